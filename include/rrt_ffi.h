@@ -1,0 +1,258 @@
+/*
+ * rrt_ffi.h -- C ABI of the MI355X (gfx950) path-tracing library `librrt_hip.so`.
+ *
+ * This is the drop-in boundary for the per-pixel hot path of Safarte/rust-ray-tracer:
+ * everything between "a Scene has been built" (reference src/scene.rs:25-30) and
+ * "an RGB8 pixel buffer exists" (reference src/main.rs:84-116).  A Rust `extern "C"`
+ * crate (or any other FFI) can bind this header verbatim: plain pointers, sizes and
+ * integer status codes only; no exceptions, panics or aborts cross the boundary.
+ *
+ * Conventions
+ *   - every entry point returns rrt_status (0 == success) unless noted;
+ *     rrt_last_error(ctx) gives a human-readable message for the last failure on ctx
+ *     (ctx may be NULL: then the last error of the calling thread outside any ctx).
+ *   - "host" pointers are ordinary process memory, copied during the call (the caller
+ *     may free them on return).  "device" pointers (d_ prefix) are HIP device memory
+ *     on the ctx's GPU; calls taking them are asynchronous on the given hipStream_t
+ *     (passed as void*; NULL == the default stream).
+ *   - one ctx per host thread, or external serialisation; one ctx drives one GPU.
+ *   - all floating point data is IEEE binary32; ids are 32-bit.
+ *
+ * Primitive ids.  The world is an ordered list of object runs (rrt_object).  Every
+ * primitive gets the id of its position in that flattened list, exactly the index it
+ * would have in the reference's world `Vec<Arc<dyn Hittable>>` in push order
+ * (reference src/gltf.rs:215-240,333-337); a cuboid contributes its 6 rectangles in
+ * the order of reference src/geometry/cuboid.rs:24-73, an instance contributes the
+ * primitives of its mesh in mesh order.  The closest hit of a ray is the minimum of
+ * (t, id) over all primitives accepted by the reference's per-primitive tests.
+ */
+#ifndef RRT_FFI_H
+#define RRT_FFI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRT_ABI_VERSION 1u
+
+typedef enum rrt_status {
+    RRT_OK = 0,
+    RRT_ERR_INVALID = 1,   /* bad argument (NULL, out-of-range index, zero size ...) */
+    RRT_ERR_NO_DEVICE = 2, /* no usable gfx950 device / HIP runtime not functional    */
+    RRT_ERR_HIP = 3,       /* a HIP call failed; message carries hipGetErrorString    */
+    RRT_ERR_OOM = 4,       /* host or device allocation failed                        */
+    RRT_ERR_IO = 5,        /* file could not be read / written                        */
+    RRT_ERR_PARSE = 6,     /* glTF / JSON / base64 content not understood             */
+    RRT_ERR_STATE = 7      /* call order wrong (e.g. render before scene upload)      */
+} rrt_status;
+
+typedef struct rrt_ctx rrt_ctx; /* opaque; owns all device memory of one GPU */
+
+/* ---- configuration (reference src/main.rs:56 MAX_DEPTH, src/ray.rs:89 t_min) ---- */
+typedef struct rrt_config {
+    int32_t device;     /* HIP device ordinal                                        */
+    uint32_t seed;      /* key of the counter-based per-pixel RNG                    */
+    uint32_t max_depth; /* reference: 4; 1..64                                       */
+    float t_min;        /* reference: 1e-4                                           */
+    uint32_t flags;     /* RRT_CFG_* bits                                            */
+} rrt_config;
+#define RRT_CFG_DEFAULT 0u
+#define RRT_CFG_COUNT_VISITS 1u /* also count BVH node visits / primitive tests (slower kernel variant) */
+
+/* ---- scene description: the reference's scene/material types as POD ---- */
+
+/* reference src/material/mod.rs:47-194 (Lambertian / Metal / Dielectric / DiffuseLight) */
+enum { RRT_MAT_LAMBERTIAN = 0, RRT_MAT_METAL = 1, RRT_MAT_DIELECTRIC = 2, RRT_MAT_DIFFUSE_LIGHT = 3 };
+typedef struct rrt_material {
+    uint32_t kind;
+    float rgb[3]; /* albedo (SolidColor), metal albedo, or emitted radiance; ignored for dielectric */
+    float param;  /* metal: fuzziness; dielectric: index of refraction; else unused                 */
+} rrt_material;
+
+/* reference src/geometry/triangle.rs:13-33 -- the library derives v0v1, v0v2 and the padded AABB itself */
+typedef struct rrt_triangle {
+    float v0[3], v1[3], v2[3];
+    uint32_t material;
+} rrt_triangle;
+
+/* reference src/geometry/sphere.rs:17-32 */
+typedef struct rrt_sphere {
+    float center[3];
+    float radius;
+    uint32_t material;
+} rrt_sphere;
+
+/* reference src/geometry/aarect.rs:14-34,69-89,145-167.  axis = the axis the plane is perpendicular to:
+ * 0: YZRect (a=y, b=z, k on x)   1: XZRect (a=x, b=z, k on y)   2: XYRect (a=x, b=y, k on z)          */
+typedef struct rrt_rect {
+    uint32_t axis;
+    float a0, a1, b0, b1, k;
+    uint32_t material;
+    uint32_t flags; /* RRT_RECT_FLIP_FACE: normal.y = -|normal.y| (reference src/geometry/mod.rs:222-234) */
+} rrt_rect;
+#define RRT_RECT_FLIP_FACE 1u
+
+/* reference src/geometry/cuboid.rs:16-77 -- expands to 6 rrt_rect in the reference's order */
+typedef struct rrt_cuboid {
+    float min[3], max[3];
+    uint32_t material;
+} rrt_cuboid;
+
+/* One entry of the ordered world list (or of a mesh's object list). */
+enum { RRT_OBJ_TRIANGLES = 0, RRT_OBJ_SPHERES = 1, RRT_OBJ_RECTS = 2, RRT_OBJ_CUBOIDS = 3, RRT_OBJ_INSTANCE = 4 };
+typedef struct rrt_object {
+    uint32_t type;  /* RRT_OBJ_*                                                          */
+    uint32_t first; /* index into the typed array (triangles / spheres / rects / cuboids / instances) */
+    uint32_t count; /* run length (must be 1 for RRT_OBJ_INSTANCE)                        */
+} rrt_object;
+
+/* A mesh = an object list of its own with its own BVH (bottom level), to be instanced.
+ * Mirrors `BVHNode::new(objects, ..)` used as the base of a transform wrapper
+ * (reference src/scene.rs:385-388).  Meshes may not contain instances.                   */
+typedef struct rrt_mesh {
+    uint32_t first_object; /* range in rrt_scene_desc.mesh_objects */
+    uint32_t object_count;
+} rrt_mesh;
+
+/* Translate(RotateY(mesh)) -- reference src/geometry/transform.rs:9-42,44-135 */
+typedef struct rrt_instance {
+    uint32_t mesh;
+    float sin_theta, cos_theta; /* RotateY: sin/cos of the angle (identity: 0, 1) */
+    float offset[3];            /* Translate offset                                */
+} rrt_instance;
+
+/* Light list entry (reference `Scene.lights`, src/scene.rs:27; sampled by src/pdf.rs:51-70).
+ * Only spheres and XZ rectangles implement pdf_value/random in the reference
+ * (src/geometry/sphere.rs:101-119, src/geometry/aarect.rs:123-142); RRT_LIGHT_OTHER keeps the
+ * trait defaults (pdf 0, direction (1,0,0); src/geometry/mod.rs:56-61).                   */
+enum { RRT_LIGHT_SPHERE = 0, RRT_LIGHT_XZRECT = 1, RRT_LIGHT_OTHER = 2 };
+typedef struct rrt_light {
+    uint32_t type;
+    float p[5]; /* sphere: cx,cy,cz,r,-   xzrect: x0,x1,z0,z1,k */
+} rrt_light;
+
+/* reference src/camera.rs:6-16 after Camera::new / apply_transform */
+typedef struct rrt_camera {
+    float c2w[12];   /* camera_to_world: 3 columns of the 3x3 part (x_axis, y_axis, z_axis), then translation */
+    float origin[3]; /* ray_origin                                                                            */
+    float scale;     /* tan(vertical_fov/2)                                                                   */
+    float aspect;    /* the CAMERA's aspect ratio (not the CLI override, reference src/main.rs:76-81)         */
+    float time0, time1;
+} rrt_camera;
+
+typedef struct rrt_scene_desc {
+    const rrt_material* materials;  uint32_t material_count;
+    const rrt_triangle* triangles;  uint32_t triangle_count;
+    const rrt_sphere* spheres;      uint32_t sphere_count;
+    const rrt_rect* rects;          uint32_t rect_count;
+    const rrt_cuboid* cuboids;      uint32_t cuboid_count;
+    const rrt_instance* instances;  uint32_t instance_count;
+    const rrt_mesh* meshes;         uint32_t mesh_count;
+    const rrt_object* mesh_objects; uint32_t mesh_object_count;
+    const rrt_object* world;        uint32_t world_count;  /* ordered world list: defines primitive ids */
+    const rrt_light* lights;        uint32_t light_count;
+    rrt_camera camera;
+    float background[3];
+} rrt_scene_desc;
+
+/* ---- ray batches (parity hook) ---- */
+typedef struct rrt_ray { /* reference src/ray.rs:14-18; direction is NOT normalised */
+    float origin[3];
+    float direction[3];
+    float time;
+} rrt_ray;
+
+typedef struct rrt_hit {
+    int32_t prim_id; /* -1: miss */
+    float t;         /* ray parameter of the hit (undefined on miss: written as +inf) */
+    float u, v;      /* HitRecord.u/.v: triangle barycentrics, rectangle uv; 0 for spheres */
+} rrt_hit;
+
+typedef struct rrt_stats {
+    uint64_t rays;        /* closest-hit queries issued by the integrator (one per reference src/ray.rs:89) */
+    uint64_t samples;     /* iterations of the spp loop, reference src/main.rs:91                           */
+    uint64_t node_visits; /* BVH nodes fetched   (only with RRT_CFG_COUNT_VISITS, else 0)                   */
+    uint64_t prim_tests;  /* primitive tests run (only with RRT_CFG_COUNT_VISITS, else 0)                   */
+    float kernel_ms;      /* HIP-event time of the render kernel on its stream                              */
+    float reserved;
+} rrt_stats;
+
+typedef struct rrt_scene_info {
+    uint32_t prim_count;     /* number of primitive ids                                   */
+    uint32_t node_count;     /* BVH nodes in HBM (all levels)                             */
+    uint32_t tri_count;      /* triangle records in HBM                                   */
+    uint32_t bvh_depth;      /* deepest leaf (top level + bottom level for instances)     */
+    uint64_t device_bytes;   /* bytes of HBM the scene occupies                           */
+    float build_ms;          /* host BVH build                                            */
+    float upload_ms;
+} rrt_scene_info;
+
+/* ---- lifetime ----  replaces: process start-up in reference src/main.rs:26-56 */
+uint32_t rrt_abi_version(void);
+rrt_status rrt_create(const rrt_config* cfg, rrt_ctx** out);
+void rrt_destroy(rrt_ctx* ctx);
+const char* rrt_last_error(const rrt_ctx* ctx);
+
+/* ---- scene upload ----  replaces: `BVHNode::new(objects, 0., 1.)` (reference src/gltf.rs:343,
+ * src/geometry/mod.rs:161-199): the library builds a flat structure-of-arrays BVH on the host
+ * and uploads it, the primitives, materials, lights and camera to HBM.                       */
+rrt_status rrt_scene_upload(rrt_ctx* ctx, const rrt_scene_desc* scene);
+rrt_status rrt_scene_get_info(const rrt_ctx* ctx, rrt_scene_info* out);
+
+/* ---- closest hit on a ray batch ----  replaces: `world.hit(ray, t_min, t_max)`
+ * (reference src/ray.rs:89 -> src/geometry/mod.rs:136-153) for n rays at once.               */
+rrt_status rrt_intersect(rrt_ctx* ctx, const rrt_ray* rays, size_t n, float t_min, float t_max, rrt_hit* out);
+rrt_status rrt_intersect_device(rrt_ctx* ctx, const rrt_ray* d_rays, size_t n, float t_min, float t_max,
+                                rrt_hit* d_out, void* stream);
+
+/* ---- render ----  replaces: the pixel loop of reference src/main.rs:86-103 (rows x columns x
+ * samples; camera.get_ray + ray_color, summed per pixel).  Sample indices
+ * [spp_offset, spp_offset + spp) of every pixel are rendered and their SUM is written to
+ * accum (w*h*3 floats, row y as in the reference's loop, i.e. bottom-up; x fastest, RGB
+ * interleaved).  Disjoint sample ranges on different GPUs add up to the full image.          */
+rrt_status rrt_render(rrt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
+                      float* accum, rrt_stats* stats);
+rrt_status rrt_render_device(rrt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
+                             float* d_accum, void* stream);
+/* Blocks until the stream of the last rrt_render_device call has drained, then reports its counters. */
+rrt_status rrt_render_stats(rrt_ctx* ctx, rrt_stats* stats);
+
+/* ---- tone map ----  replaces: `get_color(color, samples)` + the flipped `put_pixel`
+ * (reference src/vec3.rs:30-53, src/main.rs:104-109).  rgb8 is top-down, w*h*3 bytes.        */
+rrt_status rrt_tonemap(rrt_ctx* ctx, const float* accum, uint32_t width, uint32_t height, uint32_t spp_total,
+                       uint8_t* rgb8);
+rrt_status rrt_tonemap_device(rrt_ctx* ctx, const float* d_accum, uint32_t width, uint32_t height,
+                              uint32_t spp_total, uint8_t* d_rgb8, void* stream);
+
+/* ---- front end helpers (host only; not accelerated) ---- */
+
+/* Scene construction from glTF -- replaces `Scene::from_gltf_file` (reference src/gltf.rs:314-351).
+ * flags == RRT_GLTF_COMPAT reproduces the reference's contract: base64 data-URI buffers only, u16
+ * indices, primitives[0] only, accessor byteOffset / byteStride ignored, mesh-node transforms ignored,
+ * camera and lights taken from `camera_light_path` (the reference hard-codes "assets/suzanne.gltf",
+ * src/gltf.rs:317; NULL means "the same file as `path`"), lights become radius-0.2 emissive spheres,
+ * |metallic| < 1e-5 -> Lambertian else Metal(fuzz = roughness), background 0.051.
+ * RRT_GLTF_EXTENDED additionally accepts external .bin buffers, accessor byteOffset / byteStride,
+ * u8/u32 indices, bakes node TRS / matrix transforms into the vertices and applies `extended_scale`. */
+#define RRT_GLTF_COMPAT 0u
+#define RRT_GLTF_EXTENDED 1u
+typedef struct rrt_gltf_options {
+    uint32_t flags;
+    float extended_scale;     /* uniform scale applied to baked vertices (EXTENDED only; 0 == 1.0) */
+    float extended_offset[3]; /* translation applied after the scale (EXTENDED only)                */
+} rrt_gltf_options;
+rrt_status rrt_gltf_load(const char* path, const char* camera_light_path, const rrt_gltf_options* opt,
+                         rrt_scene_desc** out);
+void rrt_scene_free(rrt_scene_desc* scene); /* frees a scene returned by rrt_gltf_load */
+
+/* Image output -- replaces `img.save(output_file)` (reference src/main.rs:116); unlike the reference,
+ * a failure to write is reported.  rgb8 top-down.                                                  */
+rrt_status rrt_png_write(const char* path, const uint8_t* rgb8, uint32_t width, uint32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_FFI_H */

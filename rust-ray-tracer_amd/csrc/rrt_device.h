@@ -1,0 +1,560 @@
+// rrt_device.h -- device functions of the path tracer (gfx950).  Compiled with -ffp-contract=off:
+// every expression below rounds exactly like the scalar f32 expression it restates, so that
+// primitive tests give the same accept/reject decisions and the same t as the reference arithmetic
+// (glam 0.20 Vec3A on SSE2: dot = (x*x' + y*y') + z*z', cross = mul, mul, sub per component,
+// normalize = v / sqrt(dot(v, v)); no fused multiply-add anywhere).
+#ifndef RRT_DEVICE_H
+#define RRT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+
+#include "rrt_layout.h"
+
+namespace rrt {
+
+struct V3 {
+    float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ V3 mulv(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }  // vec3.rs:5-7
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float length_squared(V3 a) { return dot(a, a); }
+__device__ __forceinline__ V3 normalize(V3 a) { return a / sqrtf(dot(a, a)); }
+__device__ __forceinline__ float comp(V3 a, uint32_t axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
+// Rust f32::signum: 1.0 for +0.0 and positives, -1.0 for -0.0 and negatives, NaN for NaN
+__device__ __forceinline__ float signum(float x) { return x != x ? x : copysignf(1.0f, x); }
+
+#define RRT_PI 3.14159274101257324f  // std::f32::consts::PI
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG: the i-th draw of sample `s` of pixel `p` under seed `k` is a pure function
+// of (k, p, s, i).  Replaces the reference's thread-local ChaCha12 `thread_rng()` whose stream
+// is OS-seeded and therefore not reproducible (reference src/main.rs:88, src/camera.rs:57 ...).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t rng_mix(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+struct Rng {
+    uint32_t k0, k1, ctr;
+};
+__host__ __device__ __forceinline__ Rng rng_init(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    Rng r;
+    uint32_t h0 = rng_mix(seed ^ 0xA511E9B3U);
+    uint32_t h1 = rng_mix(h0 + pixel);
+    r.k0 = rng_mix(h1 ^ (sample * 0x9E3779B9U));
+    r.k1 = rng_mix(r.k0 ^ 0x68E31DA4U ^ pixel);
+    r.ctr = 0;
+    return r;
+}
+__host__ __device__ __forceinline__ uint32_t rng_u32(Rng& r) {
+    uint32_t x = r.k0 + r.ctr * 0x9E3779B9U;
+    r.ctr++;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x ^= r.k1; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// rand 0.8 `Standard` for f32: 24 random bits scaled into [0, 1)
+__device__ __forceinline__ float rng_f32(Rng& r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
+// rand 0.8 `gen_range(lo..hi)` for f32 (UniformFloat::sample_single): 23 bits into [1,2), minus 1, scale, offset
+__device__ __forceinline__ float rng_range(Rng& r, float lo, float hi) {
+    const float scale = hi - lo;
+    for (int tries = 0; tries < 8; ++tries) {
+        float v12 = __uint_as_float((rng_u32(r) >> 9) | 0x3f800000U);
+        float res = (v12 - 1.0f) * scale + lo;
+        if (res < hi) return res;
+    }
+    return lo;
+}
+// rand 0.8 `gen_bool(0.5)`: a u64 draw compared with 2^63, i.e. one fair bit
+__device__ __forceinline__ bool rng_bool_half(Rng& r) { return (rng_u32(r) >> 31) == 0u; }
+// rand 0.8 `gen_range(0..n)`: unbiased integer in [0, n) (widening multiply with rejection)
+__device__ __forceinline__ uint32_t rng_index(Rng& r, uint32_t n) {
+    const uint32_t zone = (uint32_t)(-(int32_t)n) % n;  // 2^32 mod n
+    for (;;) {
+        uint64_t m = (uint64_t)rng_u32(r) * (uint64_t)n;
+        if ((uint32_t)m >= zone) return (uint32_t)(m >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Orthonormal basis -- reference src/vec3.rs:55-73 with glam's any_orthonormal_pair (Duff et al.)
+// ---------------------------------------------------------------------------------------------
+struct Onb {
+    V3 u, v, w;
+};
+__device__ __forceinline__ Onb onb_from_w(V3 n) {
+    Onb o;
+    o.w = normalize(n);
+    const float sign = copysignf(1.0f, o.w.z);
+    const float a = -1.0f / (sign + o.w.z);
+    const float b = o.w.x * o.w.y * a;
+    o.u = v3(1.0f + sign * o.w.x * o.w.x * a, sign * b, -sign * o.w.x);
+    o.v = v3(b, sign + o.w.y * o.w.y * a, -o.w.y);
+    return o;
+}
+__device__ __forceinline__ V3 onb_local(const Onb& o, V3 a) { return (a.x * o.u + a.y * o.v) + a.z * o.w; }
+
+// ---------------------------------------------------------------------------------------------
+// Primitive tests.  Each returns true and updates (tbest, best_id, ...) iff the reference test
+// accepts the hit in [tmin, tbest] and (t, id) is lexicographically below the current best.
+// ---------------------------------------------------------------------------------------------
+struct Best {
+    float t;        // closest t so far (starts at the query's t_max)
+    uint32_t id;    // primitive id of the closest hit (0xFFFFFFFF: none)
+    float u, v;
+    uint32_t what;  // kind << 28 | record index
+    int32_t inst;   // instance record the hit lies in, -1 for top-level primitives
+};
+
+__device__ __forceinline__ bool better(float t, uint32_t id, const Best& b) { return t < b.t || id < b.id; }
+
+// reference src/geometry/triangle.rs:38-69
+__device__ __forceinline__ void test_triangle(const TriRec* __restrict__ tris, uint32_t idx, V3 o, V3 d, float tmin,
+                                              uint32_t id_base, int32_t inst, Best& best) {
+    const float4 q0 = *reinterpret_cast<const float4*>(&tris[idx].v0[0]);
+    const float4 q1 = *reinterpret_cast<const float4*>(&tris[idx].e1[0]);
+    const float4 q2 = *reinterpret_cast<const float4*>(&tris[idx].e2[0]);
+    const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q1.x, q1.y, q1.z), e2 = v3(q2.x, q2.y, q2.z);
+    const V3 pvec = cross(d, e2);
+    const float det = dot(e1, pvec);
+    if (det > 1e-5f) {
+        const float inv_det = 1.0f / det;
+        const V3 tvec = o - v0;
+        const float u = dot(tvec, pvec) * inv_det;
+        if (u >= 0.0f && u <= 1.0f) {
+            const V3 qvec = cross(tvec, e1);
+            const float v = dot(d, qvec) * inv_det;
+            if (v >= 0.0f && v < 1.0f - u) {
+                const float t = dot(e2, qvec) * inv_det;
+                if (t >= tmin && t <= best.t) {
+                    const uint32_t id = id_base + __float_as_uint(q0.w);
+                    if (better(t, id, best)) {
+                        best.t = t; best.id = id; best.u = u; best.v = v;
+                        best.what = (KIND_TRI << 28) | idx; best.inst = inst;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// reference src/geometry/sphere.rs:52-95; returns the accepted root or NaN
+__device__ __forceinline__ float sphere_root(V3 c, float radius, V3 o, V3 d, float tmin, float tmax) {
+    const V3 oc = o - c;
+    const float a = length_squared(d);
+    const float b = dot(oc, d);
+    const float cc = length_squared(oc) - radius * radius;
+    const float disc = b * b - a * cc;
+    if (disc > 0.0f) {
+        const float sq = sqrtf(disc);
+        float root = (-b - sq) / a;
+        if (tmin <= root && root <= tmax) return root;
+        root = (-b + sq) / a;
+        if (tmin <= root && root <= tmax) return root;
+    }
+    return __uint_as_float(0x7fc00000U);
+}
+
+__device__ __forceinline__ void test_sphere(const SphereRec* __restrict__ spheres, uint32_t idx, V3 o, V3 d, float tmin,
+                                            uint32_t id_base, int32_t inst, Best& best) {
+    const float4 q0 = *reinterpret_cast<const float4*>(&spheres[idx].c[0]);
+    const uint32_t lid = spheres[idx].id;
+    const float t = sphere_root(v3(q0.x, q0.y, q0.z), q0.w, o, d, tmin, best.t);
+    if (t == t) {
+        const uint32_t id = id_base + lid;
+        if (better(t, id, best)) {
+            best.t = t; best.id = id; best.u = 0.0f; best.v = 0.0f;
+            best.what = (KIND_SPHERE << 28) | idx; best.inst = inst;
+        }
+    }
+}
+
+// reference src/geometry/aarect.rs:39-58 (XY), 94-113 (XZ), 170-189 (YZ)
+__device__ __forceinline__ void rect_axes(uint32_t axis, uint32_t& ia, uint32_t& ib) {
+    // axis 0: YZRect (a = y, b = z); axis 1: XZRect (a = x, b = z); axis 2: XYRect (a = x, b = y)
+    ia = axis == 0 ? 1u : 0u;
+    ib = axis == 2 ? 1u : 2u;
+}
+__device__ __forceinline__ bool rect_hit(float a0, float a1, float b0, float b1, float k, uint32_t axis, V3 o, V3 d,
+                                         float tmin, float tmax, float& t_out, float& u_out, float& v_out) {
+    uint32_t ia, ib;
+    rect_axes(axis, ia, ib);
+    const float t = (k - comp(o, axis)) / comp(d, axis);
+    if (t >= tmin && t <= tmax) {
+        const float a = comp(o, ia) + t * comp(d, ia);
+        const float b = comp(o, ib) + t * comp(d, ib);
+        if (a >= a0 && a <= a1 && b >= b0 && b <= b1) {
+            t_out = t;
+            u_out = (a - a0) / (a1 - a0);
+            v_out = (b - b0) / (b1 - b0);
+            return true;
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ void test_rect(const RectRec* __restrict__ rects, uint32_t idx, V3 o, V3 d, float tmin,
+                                          uint32_t id_base, int32_t inst, Best& best) {
+    const float4 q0 = *reinterpret_cast<const float4*>(&rects[idx].a0);
+    const float4 q1 = *reinterpret_cast<const float4*>(&rects[idx].k);
+    float t, u, v;
+    if (rect_hit(q0.x, q0.y, q0.z, q0.w, q1.x, __float_as_uint(q1.y) & 3u, o, d, tmin, best.t, t, u, v)) {
+        const uint32_t id = id_base + __float_as_uint(q1.z);
+        if (better(t, id, best)) {
+            best.t = t; best.id = id; best.u = u; best.v = v;
+            best.what = (KIND_RECT << 28) | idx; best.inst = inst;
+        }
+    }
+}
+
+// RotateY then Translate, applied to a ray -- reference src/geometry/transform.rs:24,101-108
+__device__ __forceinline__ void to_object_space(const InstRec& in, V3 o, V3 d, V3& oo, V3& od) {
+    const V3 m = o - v3(in.offset[0], in.offset[1], in.offset[2]);
+    oo = v3(in.cos_t * m.x - in.sin_t * m.z, m.y, in.sin_t * m.x + in.cos_t * m.z);
+    od = v3(in.cos_t * d.x - in.sin_t * d.z, d.y, in.sin_t * d.x + in.cos_t * d.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// BVH traversal: closest hit = min (t, id) over the reference's per-primitive tests.
+// The slab test is conservative: t values carry at most 3 roundings (subtract, multiply, and the
+// reciprocal), covered by widening the far side by 2^-21 relative (Ize, "Robust BVH Ray Traversal").
+// NaN slabs (0 * inf) drop out of min/max and count as hits, like f32::max/min in the reference's
+// src/bvh/aabb.rs:24-28.
+// `stack` points at this lane's slot of the LDS stack; entries are `stride` ints apart.
+// ---------------------------------------------------------------------------------------------
+struct TraceCounters {
+    uint32_t nodes, prims;
+};
+
+template <bool INST, bool COUNT>
+__device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin, float tmax, int* stack, int stride,
+                                      Best& best, TraceCounters& cnt) {
+    best.t = tmax; best.id = 0xFFFFFFFFu; best.u = 0.f; best.v = 0.f; best.what = 0u; best.inst = -1;
+    const float far_scale = 1.0000005f;
+
+    V3 ro = o, rd = d;  // ray in the space being traversed (world, or an instance's object space)
+    V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    uint32_t id_base = 0;
+    int32_t cur_inst = -1;
+
+    int sp = 0;
+    stack[0] = REF_DONE;
+    sp = 1;
+    int cur = S.root;
+
+    for (;;) {
+        // ---- inner nodes
+        while (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+            if (COUNT) cnt.nodes++;
+            // left box
+            float t0x = (a.x - ro.x) * inv.x, t1x = (a.w - ro.x) * inv.x;
+            float t0y = (a.y - ro.y) * inv.y, t1y = (b.x - ro.y) * inv.y;
+            float t0z = (a.z - ro.z) * inv.z, t1z = (b.y - ro.z) * inv.z;
+            float ln = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+            float lf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
+            lf = fminf(lf, best.t);
+            // right box
+            t0x = (b.z - ro.x) * inv.x; t1x = (c.y - ro.x) * inv.x;
+            t0y = (b.w - ro.y) * inv.y; t1y = (c.z - ro.y) * inv.y;
+            t0z = (c.x - ro.z) * inv.z; t1z = (c.w - ro.z) * inv.z;
+            float rn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+            float rf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
+            rf = fminf(rf, best.t);
+            const bool hl = ln <= lf, hr = rn <= rf;
+            int left = __float_as_int(e.x), right = __float_as_int(e.y);
+            if (hl && hr) {
+                if (rn < ln) { int tmp = left; left = right; right = tmp; }
+                stack[sp * stride] = right;
+                sp++;
+                cur = left;
+            } else if (hl) {
+                cur = left;
+            } else if (hr) {
+                cur = right;
+            } else {
+                sp--;
+                cur = stack[sp * stride];
+            }
+        }
+        if (cur == REF_DONE) break;
+
+        // ---- leaf (or marker)
+        const uint32_t ref = (uint32_t)cur;
+        const uint32_t kind = (ref >> 28) & 7u;
+        const uint32_t first = ref & REF_OFFSET_MASK;
+        if (kind == KIND_TRI) {
+            const uint32_t count = ((ref >> 25) & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                test_triangle(S.tris, first + k, ro, rd, tmin, id_base, cur_inst, best);
+            }
+            if (COUNT) cnt.prims += count;
+        } else if (kind == KIND_SPHERE) {
+            test_sphere(S.spheres, first, ro, rd, tmin, id_base, cur_inst, best);
+            if (COUNT) cnt.prims++;
+        } else if (kind == KIND_RECT) {
+            test_rect(S.rects, first, ro, rd, tmin, id_base, cur_inst, best);
+            if (COUNT) cnt.prims++;
+        } else if (INST && kind == KIND_INST) {
+            const InstRec in = S.insts[first];
+            to_object_space(in, o, d, ro, rd);
+            inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            id_base = in.id_base;
+            cur_inst = (int32_t)first;
+            stack[sp * stride] = REF_INST_EXIT;
+            sp++;
+            cur = in.root;
+            continue;
+        } else if (INST && kind == KIND_INST_EXIT) {
+            ro = o; rd = d;
+            inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            id_base = 0;
+            cur_inst = -1;
+        }
+        sp--;
+        cur = stack[sp * stride];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Surface record of the closest hit -- what the reference's HitRecord carries
+// (src/material/mod.rs:18-25): p, normal, material.
+// ---------------------------------------------------------------------------------------------
+struct Surface {
+    V3 p, n;
+    uint32_t material;
+};
+
+__device__ __forceinline__ Surface surface_at(const SceneDev& S, const Best& best, V3 o, V3 d) {
+    Surface s;
+    V3 ro = o, rd = d;
+    InstRec in;
+    const bool instanced = best.inst >= 0;
+    if (instanced) {
+        in = S.insts[best.inst];
+        to_object_space(in, o, d, ro, rd);
+    }
+    const uint32_t kind = best.what >> 28, idx = best.what & REF_OFFSET_MASK;
+    s.p = ro + best.t * rd;  // Ray::at, src/ray.rs:41-43
+    if (kind == KIND_TRI) {
+        const float4 q1 = *reinterpret_cast<const float4*>(&S.tris[idx].e1[0]);
+        const float4 q2 = *reinterpret_cast<const float4*>(&S.tris[idx].e2[0]);
+        // det > 1e-5 on every accepted hit, so det.signum() == 1 (triangle.rs:42,58)
+        s.n = normalize(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));
+        s.material = __float_as_uint(q1.w);
+    } else if (kind == KIND_SPHERE) {
+        const float4 q0 = *reinterpret_cast<const float4*>(&S.spheres[idx].c[0]);
+        s.n = (s.p - v3(q0.x, q0.y, q0.z)) / q0.w;  // sphere.rs:65,86
+        s.material = S.spheres[idx].material;
+    } else {
+        const float4 q1 = *reinterpret_cast<const float4*>(&S.rects[idx].k);
+        const uint32_t af = __float_as_uint(q1.y);
+        const uint32_t axis = af & 3u;
+        const float sg = signum(comp(ro, axis) - q1.x);  // aarect.rs:49,104,180
+        s.n = v3(axis == 0 ? sg : 0.0f, axis == 1 ? sg : 0.0f, axis == 2 ? sg : 0.0f);
+        if (af & 0x100u) s.n.y = -fabsf(s.n.y);  // FlipFace, geometry/mod.rs:226-230
+        s.material = __float_as_uint(q1.w);
+    }
+    if (instanced) {
+        // RotateY::hit, transform.rs:113-124 (the sign test mixes the rotated-back normal with the
+        // object-space direction, exactly as the reference does), then Translate::hit, transform.rs:27
+        const V3 p = v3(in.cos_t * s.p.x + in.sin_t * s.p.z, s.p.y, -in.sin_t * s.p.x + in.cos_t * s.p.z);
+        const V3 n = v3(in.cos_t * s.n.x + in.sin_t * s.n.z, s.n.y, -in.sin_t * s.n.x + in.cos_t * s.n.z);
+        s.n = (-n) * signum(dot(n, rd));
+        s.p = p + v3(in.offset[0], in.offset[1], in.offset[2]);
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Camera -- reference src/camera.rs:56-69.  (x, y) already contain the pixel jitter; the second
+// half-pixel offset below is the reference's.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void camera_ray(const CameraRec& cam, float x, float y, uint32_t w, uint32_t h, V3& o, V3& d) {
+    const float px = (2.0f * (x + 0.5f) / (float)w - 1.0f) * cam.scale * cam.aspect;
+    const float py = (2.0f * (y + 0.5f) / (float)h - 1.0f) * cam.scale;
+    const V3 c0 = v3(cam.c0[0], cam.c0[1], cam.c0[2]), c1 = v3(cam.c1[0], cam.c1[1], cam.c1[2]);
+    const V3 c2 = v3(cam.c2[0], cam.c2[1], cam.c2[2]), tr = v3(cam.tr[0], cam.tr[1], cam.tr[2]);
+    const V3 ray_p = ((c0 * px + c1 * py) + c2 * (-1.0f)) + tr;  // Affine3A::transform_point3a
+    o = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    d = ray_p - o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Light list -- reference src/geometry/mod.rs:111-125 over src/geometry/sphere.rs:101-119,217-228
+// and src/geometry/aarect.rs:123-142
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 lights_random(const SceneDev& S, V3 origin, Rng& rng) {
+    const uint32_t pick = rng_index(rng, S.light_count);
+    const LightRec L = S.lights[pick];
+    if (L.type == 0u) {
+        const V3 direction = v3(L.p0, L.p1, L.p2) - origin;
+        const float dist2 = length_squared(direction);
+        const Onb uvw = onb_from_w(direction);
+        const float r1 = rng_f32(rng);
+        const float r2 = rng_f32(rng);
+        const float z = 1.0f + r2 * (sqrtf(1.0f - L.p3 * L.p3 / dist2) - 1.0f);
+        const float phi = 2.0f * RRT_PI * r1;
+        float sn, cs;
+        sincosf(phi, &sn, &cs);
+        const float x = cs * sqrtf(1.0f - z * z);
+        const float y = sn * sqrtf(1.0f - z * z);
+        return onb_local(uvw, v3(x, y, z));
+    } else if (L.type == 1u) {
+        const float rx = rng_range(rng, L.p0, L.p1);
+        const float rz = rng_range(rng, L.p2, L.p3);
+        return v3(rx, L.p4, rz) - origin;
+    }
+    return v3(1.0f, 0.0f, 0.0f);
+}
+
+__device__ __forceinline__ float lights_pdf(const SceneDev& S, V3 origin, V3 v) {
+    const float weight = 1.0f / (float)S.light_count;
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < S.light_count; ++i) {
+        const LightRec L = S.lights[i];
+        float pdf = 0.0f;
+        if (L.type == 0u) {
+            const V3 c = v3(L.p0, L.p1, L.p2);
+            const float root = sphere_root(c, L.p3, origin, v, 0.0001f, __builtin_inff());
+            if (root == root) {
+                const float cos_theta_max = sqrtf(1.0f - L.p3 * L.p3 / length_squared(c - origin));
+                const float solid_angle = 2.0f * RRT_PI * (1.0f - cos_theta_max);
+                pdf = 1.0f / solid_angle;
+            }
+        } else if (L.type == 1u) {
+            float t, uu, vv;
+            if (rect_hit(L.p0, L.p1, L.p2, L.p3, L.p4, 1u, origin, v, 0.001f, __builtin_inff(), t, uu, vv)) {
+                const float area = (L.p1 - L.p0) * (L.p3 - L.p2);
+                const float dist2 = t * t * length_squared(v);
+                const V3 n = v3(0.0f, signum(origin.y - L.p4), 0.0f);
+                const float cosine = fabsf(dot(v, n)) / sqrtf(length_squared(v));
+                pdf = dist2 / (cosine * area);
+            }
+        }
+        sum += weight * pdf;
+    }
+    return sum;
+}
+
+// reference src/pdf.rs:14-26
+__device__ __forceinline__ V3 random_cosine_direction(Rng& rng) {
+    const float r1 = rng_f32(rng);
+    const float r2 = rng_f32(rng);
+    const float z = sqrtf(1.0f - r2);
+    const float phi = 2.0f * RRT_PI * r1;
+    const float sr2 = sqrtf(r2);
+    float sn, cs;
+    sincosf(phi, &sn, &cs);
+    return v3(cs * sr2, sn * sr2, z);
+}
+
+// reference src/vec3.rs:9-25
+__device__ __forceinline__ V3 random_in_unit_sphere(Rng& rng) {
+    for (;;) {
+        const float x = rng_range(rng, -1.0f, 1.0f);
+        const float y = rng_range(rng, -1.0f, 1.0f);
+        const float z = rng_range(rng, -1.0f, 1.0f);
+        const V3 p = v3(x, y, z);
+        if (length_squared(p) < 1.0f) return p;
+    }
+}
+
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - (2.0f * dot(v, n)) * n; }  // material/mod.rs:150-152
+
+// x^5 the way llvm.powi / compiler-rt __powisf2 evaluates it: x * ((x*x)*(x*x))
+__device__ __forceinline__ float powi5(float x) {
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    return x * x4;
+}
+
+// One bounce of the reference's recursive `ray_color` (src/ray.rs:78-127), in throughput form:
+//   radiance += beta * emitted;  beta *= weight;  ray = scattered;   (returns false when the path ends)
+__device__ __forceinline__ bool shade(const SceneDev& S, const Surface& sf, V3& o, V3& d, V3& beta, V3& radiance,
+                                      Rng& rng) {
+    const float4 m0 = *reinterpret_cast<const float4*>(&S.mats[sf.material].kind);
+    const uint32_t kind = __float_as_uint(m0.x);
+    const V3 rgb = v3(m0.y, m0.z, m0.w);
+    if (kind == 3u) {  // DiffuseLight, material/mod.rs:183-194: no scatter, emits towards the front face only
+        if (dot(d, sf.n) < 0.0f) radiance = radiance + mulv(beta, rgb);
+        return false;
+    }
+    if (kind == 0u) {  // Lambertian, material/mod.rs:71-84 + mixture sampling, ray.rs:99-120
+        const Onb uvw = onb_from_w(sf.n);
+        V3 dir;
+        float pdf_val;
+        if (S.light_count != 0u) {
+            if (rng_bool_half(rng)) dir = onb_local(uvw, random_cosine_direction(rng));  // pdf.rs:87-94
+            else dir = lights_random(S, sf.p, rng);
+            const float cosine = dot(normalize(dir), uvw.w);
+            const float cos_pdf = fmaxf(cosine / RRT_PI, 0.0f);
+            pdf_val = 0.5f * cos_pdf + 0.5f * lights_pdf(S, sf.p, dir);
+        } else {
+            dir = onb_local(uvw, random_cosine_direction(rng));
+            const float cosine = dot(normalize(dir), uvw.w);
+            pdf_val = fmaxf(cosine / RRT_PI, 0.0f);
+        }
+        pdf_val = fmaxf(pdf_val, 1e-5f);
+        const float s_pdf = fmaxf(dot(sf.n, normalize(dir)) / RRT_PI, 0.0f);
+        // emitted == 0 for Lambertian;  L = s_pdf * (albedo * L_next) / pdf_val
+        beta = mulv(beta, (s_pdf * rgb) / pdf_val);
+        o = sf.p;
+        d = dir;
+        return true;
+    }
+    if (kind == 1u) {  // Metal, material/mod.rs:91-108
+        const float fuzz = S.mats[sf.material].param;
+        const V3 reflected = reflect(normalize(d), sf.n);
+        const V3 dir = reflected + fuzz * random_in_unit_sphere(rng);
+        if (dot(dir, sf.n) > 0.0f) {
+            beta = mulv(beta, rgb);
+            o = sf.p;
+            d = dir;
+            return true;
+        }
+        return false;  // absorbed: scatter None, emitted 0
+    }
+    {  // Dielectric, material/mod.rs:114-148
+        const float ir = S.mats[sf.material].param;
+        float ratio = 1.0f / ir;
+        V3 n = sf.n;
+        if (dot(d, sf.n) > 0.0f) {
+            ratio = ir;
+            n = -sf.n;
+        }
+        const V3 unit = normalize(d);
+        const float cos_theta = -fminf(dot(unit, n), 1.0f);
+        // refract(), material/mod.rs:154-163
+        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool refracted = false;
+        V3 out;
+        if (!(ratio * sin_theta > 1.0f)) {
+            const V3 r_out_ortho = ratio * (unit + cos_theta * n);
+            const V3 r_out_para = (-sqrtf(fabsf(1.0f - length_squared(r_out_ortho)))) * n;
+            const float r0 = (1.0f - ir) / (1.0f + ir);
+            const float r0s = r0 * r0;
+            const float reflectance = r0s + (1.0f - r0s) * powi5(1.0f - cos_theta);
+            if (reflectance < rng_f32(rng)) {
+                refracted = true;
+                out = r_out_ortho + r_out_para;
+            }
+        }
+        if (!refracted) out = reflect(unit, sf.n);
+        o = sf.p;
+        d = out;
+        return true;  // attenuation (1,1,1)
+    }
+}
+
+}  // namespace rrt
+#endif

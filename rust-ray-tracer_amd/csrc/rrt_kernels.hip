@@ -1,0 +1,208 @@
+// rrt_kernels.hip -- gfx950 kernels: path-tracing megakernel, ray-batch closest hit, tone map.
+//
+// k_render: one lane owns one pixel; one 64-lane wavefront owns an 8x8 pixel tile.  A lane runs the
+// reference's per-pixel loop (src/main.rs:87-103) flattened over (sample, bounce): every loop trip
+// traces exactly one ray, and a lane whose path ended starts its next sample at once, so lanes are
+// never parked waiting for the longest path in the wave.  The radiance sum stays in registers and is
+// written once (12 bytes per pixel).  Traversal stacks live in LDS (STACK_DEPTH dwords per lane,
+// [entry][lane] so that a wave access touches 64 consecutive banks).
+#include <hip/hip_runtime.h>
+
+#include "rrt_device.h"
+#include "rrt_kernels.h"
+
+namespace rrt {
+
+static constexpr int WAVE = 64;
+
+// Workgroup id -> tile index such that the workgroups dealt to one XCD (ids congruent mod 8) cover a
+// contiguous range of tiles: the 4 MiB L2 of an XCD then sees one eighth of the image.  Bijective for
+// any tile count.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
+    const uint32_t q = n / 8u, r = n % 8u;
+    const uint32_t xcd = bid % 8u, idx = bid / 8u;
+    const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+template <bool INST, bool COUNT>
+__global__ __launch_bounds__(WAVE) void k_render(SceneDev S, uint32_t width, uint32_t height, uint32_t spp,
+                                                 uint32_t spp_offset, uint32_t tiles_x, uint32_t n_tiles,
+                                                 float* __restrict__ accum, unsigned long long* __restrict__ counters) {
+    __shared__ int s_stack[STACK_DEPTH * WAVE];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    const bool inside = x < width && y < height;
+    int* stack = s_stack + lane;
+
+    const uint32_t pixel = y * width + x;
+    const V3 bg = v3(S.background[0], S.background[1], S.background[2]);
+    V3 sum = v3(0.f, 0.f, 0.f);
+    uint32_t n_rays = 0;
+    TraceCounters cnt = {0u, 0u};
+
+    uint32_t s = inside ? 0u : spp;  // sample counter of this lane
+    V3 o, d, beta, radiance;
+    uint32_t depth = 0;
+    Rng rng;
+    if (s < spp) {
+        rng = rng_init(S.seed, pixel, spp_offset + s);
+        const float u = (float)x + rng_f32(rng);  // main.rs:92-93
+        const float v = (float)y + rng_f32(rng);
+        rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
+        camera_ray(S.cam, u, v, width, height, o, d);
+        beta = v3(1.f, 1.f, 1.f);
+        radiance = v3(0.f, 0.f, 0.f);
+        depth = S.max_depth;
+    }
+
+    while (s < spp) {
+        Best best;
+        trace<INST, COUNT>(S, o, d, S.t_min, __builtin_inff(), stack, WAVE, best, cnt);
+        n_rays++;
+        bool alive;
+        if (best.id == 0xFFFFFFFFu) {
+            radiance = radiance + mulv(beta, bg);  // ray.rs:126
+            alive = false;
+        } else {
+            const Surface sf = surface_at(S, best, o, d);
+            alive = shade(S, sf, o, d, beta, radiance, rng);
+        }
+        depth--;
+        if (depth == 0u) alive = false;  // ray.rs:85-87: depth 0 contributes black
+        if (!alive) {
+            sum = sum + radiance;  // main.rs:95
+            s++;
+            if (s < spp) {
+                rng = rng_init(S.seed, pixel, spp_offset + s);
+                const float u = (float)x + rng_f32(rng);
+                const float v = (float)y + rng_f32(rng);
+                rng.ctr++;
+                camera_ray(S.cam, u, v, width, height, o, d);
+                beta = v3(1.f, 1.f, 1.f);
+                radiance = v3(0.f, 0.f, 0.f);
+                depth = S.max_depth;
+            }
+        }
+    }
+
+    if (inside) {
+        float* px = accum + 3ull * pixel;
+        px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
+    }
+    const unsigned long long rays = wave_sum((unsigned long long)n_rays);
+    if (COUNT) {
+        const unsigned long long nn = wave_sum((unsigned long long)cnt.nodes);
+        const unsigned long long np = wave_sum((unsigned long long)cnt.prims);
+        if (lane == 0) { atomicAdd(&counters[1], nn); atomicAdd(&counters[2], np); }
+    }
+    if (lane == 0) atomicAdd(&counters[0], rays);
+}
+
+// Closest hit for a batch of rays: one lane per ray.  Sphere uv follows the reference's
+// get_sphere_uv (src/geometry/sphere.rs:34-40), including its far-root call with the un-normalised p.
+template <bool INST>
+__global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* __restrict__ rays, size_t n, float tmin,
+                                                    float tmax, rrt_hit* __restrict__ out) {
+    __shared__ int s_stack[STACK_DEPTH * WAVE];
+    const size_t i = (size_t)blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    const rrt_ray r = rays[i];
+    const V3 o = v3(r.origin[0], r.origin[1], r.origin[2]);
+    const V3 d = v3(r.direction[0], r.direction[1], r.direction[2]);
+    Best best;
+    TraceCounters cnt = {0u, 0u};
+    trace<INST, false>(S, o, d, tmin, tmax, s_stack + threadIdx.x, WAVE, best, cnt);
+    rrt_hit h;
+    if (best.id == 0xFFFFFFFFu) {
+        h.prim_id = -1; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f;
+    } else {
+        h.prim_id = (int32_t)best.id; h.t = best.t; h.u = best.u; h.v = best.v;
+        if ((best.what >> 28) == KIND_SPHERE) {
+            const uint32_t idx = best.what & REF_OFFSET_MASK;
+            V3 ro = o, rd = d;
+            if (best.inst >= 0) to_object_space(S.insts[best.inst], o, d, ro, rd);
+            const float4 q0 = *reinterpret_cast<const float4*>(&S.spheres[idx].c[0]);
+            const V3 c = v3(q0.x, q0.y, q0.z);
+            const V3 p = ro + best.t * rd;
+            // which root was it?  recompute the near root exactly as sphere_root does
+            const V3 oc = ro - c;
+            const float a = length_squared(rd), b = dot(oc, rd), cc = length_squared(oc) - q0.w * q0.w;
+            const float sq = sqrtf(b * b - a * cc);
+            const float near_root = (-b - sq) / a;
+            const V3 q = (near_root == best.t) ? (p - c) / q0.w : p;
+            const float theta = acosf(-q.y);
+            const float phi = atan2f(-q.z, q.x) + RRT_PI;
+            h.u = phi / (2.0f * RRT_PI);
+            h.v = theta / RRT_PI;
+        }
+    }
+    out[i] = h;
+}
+
+// get_color + flipped put_pixel -- reference src/vec3.rs:30-53, src/main.rs:104-109
+__global__ void k_tonemap(const float* __restrict__ accum, uint32_t width, uint32_t height, uint32_t spp,
+                          uint8_t* __restrict__ rgb8) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= width * height) return;
+    const uint32_t x = i % width, y = i / width;
+    const float scale = 1.0f / (float)spp;
+    uint8_t* px = rgb8 + 3ull * ((size_t)(height - 1u - y) * width + x);
+    for (int c = 0; c < 3; ++c) {
+        const float v = accum[3ull * i + c];
+        float g = (v != v) ? 0.0f : sqrtf(v * scale);
+        // f32::clamp keeps NaN; `as u8` saturates and maps NaN to 0
+        float cl = g;
+        if (cl < 0.0f) cl = 0.0f;
+        if (cl > 0.999f) cl = 0.999f;
+        const float q = 256.0f * cl;
+        px[c] = (q != q) ? (uint8_t)0 : (uint8_t)(int)q;
+    }
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+
+hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
+                         float* d_accum, unsigned long long* d_counters, bool count_visits, hipStream_t stream) {
+    const uint32_t tiles_x = (width + 7u) / 8u, tiles_y = (height + 7u) / 8u;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    dim3 grid(n_tiles), block(WAVE);
+    const bool inst = S.has_instances != 0u;
+    if (inst && count_visits)
+        hipLaunchKernelGGL((k_render<true, true>), grid, block, 0, stream, S, width, height, spp, spp_offset, tiles_x, n_tiles, d_accum, d_counters);
+    else if (inst)
+        hipLaunchKernelGGL((k_render<true, false>), grid, block, 0, stream, S, width, height, spp, spp_offset, tiles_x, n_tiles, d_accum, d_counters);
+    else if (count_visits)
+        hipLaunchKernelGGL((k_render<false, true>), grid, block, 0, stream, S, width, height, spp, spp_offset, tiles_x, n_tiles, d_accum, d_counters);
+    else
+        hipLaunchKernelGGL((k_render<false, false>), grid, block, 0, stream, S, width, height, spp, spp_offset, tiles_x, n_tiles, d_accum, d_counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, float tmin, float tmax, rrt_hit* d_out,
+                            hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
+    if (S.has_instances)
+        hipLaunchKernelGGL((k_intersect<true>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
+    else
+        hipLaunchKernelGGL((k_intersect<false>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb8,
+                          hipStream_t stream) {
+    const uint32_t n = width * height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tonemap, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_accum, width, height, spp, d_rgb8);
+    return hipGetLastError();
+}
+
+}  // namespace rrt

@@ -1,0 +1,123 @@
+// rrt_layout.h -- layout of the scene as it lives in HBM (shared by the host builder and the kernels).
+//
+// Everything a ray touches during traversal is a 16-byte-aligned record read with
+// global_load_dwordx4:
+//   BvhNode   64 B  both child boxes + both child references (the idea of the reference's
+//                   unfinished flat BVH, src/bvh/mod.rs:19-25: a node stores its children's boxes)
+//   TriRec    48 B  v0 | id, v0v1 | material, v0v2 | -      (reference src/geometry/triangle.rs:13-20)
+//   SphereRec 32 B  centre, radius | id, material           (reference src/geometry/sphere.rs:17-22)
+//   RectRec   32 B  a0,a1,b0,b1 | k, axis+flags, id, material (reference src/geometry/aarect.rs:14-21)
+//   InstRec   48 B  Translate(RotateY(mesh))                (reference src/geometry/transform.rs:9-12,44-49)
+//   MatRec    32 B  kind, rgb, param                        (reference src/material/mod.rs:47-194)
+#ifndef RRT_LAYOUT_H
+#define RRT_LAYOUT_H
+
+#include <stdint.h>
+
+namespace rrt {
+
+// Child reference encoding (int32):
+//   >= 0                 : index of an inner node
+//   bit31 set            : leaf;  bits 30..28 = kind, bits 27..25 = count-1 (triangles), bits 24..0 = first record
+static constexpr uint32_t REF_LEAF = 0x80000000u;
+static constexpr uint32_t KIND_TRI = 0u, KIND_SPHERE = 1u, KIND_RECT = 2u, KIND_INST = 3u;
+static constexpr uint32_t KIND_EMPTY = 5u;      // child slot without content (scenes with fewer than two primitives)
+static constexpr uint32_t KIND_INST_EXIT = 6u;  // traversal stack marker: leave the instance's object space
+static constexpr uint32_t KIND_DONE = 7u;       // traversal stack marker: bottom of stack / empty child
+static constexpr uint32_t REF_OFFSET_MASK = 0x01FFFFFFu;
+static constexpr uint32_t MAX_LEAF_TRIS = 8u;
+static constexpr int32_t REF_DONE = (int32_t)(REF_LEAF | (KIND_DONE << 28));
+static constexpr int32_t REF_INST_EXIT = (int32_t)(REF_LEAF | (KIND_INST_EXIT << 28));
+
+static inline uint32_t make_leaf_ref(uint32_t kind, uint32_t first, uint32_t count) {
+    return REF_LEAF | (kind << 28) | (((count - 1u) & 7u) << 25) | (first & REF_OFFSET_MASK);
+}
+
+struct alignas(16) BvhNode {
+    // a = (L.min.x, L.min.y, L.min.z, L.max.x)  b = (L.max.y, L.max.z, R.min.x, R.min.y)
+    // c = (R.min.z, R.max.x, R.max.y, R.max.z)  d = (left ref, right ref, 0, 0)
+    float lmin[3];
+    float lmax[3];
+    float rmin[3];
+    float rmax[3];
+    int32_t left, right;
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+struct alignas(16) TriRec {
+    float v0[3];   uint32_t id;
+    float e1[3];   uint32_t material;  // v0v1 = v1 - v0
+    float e2[3];   uint32_t pad;       // v0v2 = v2 - v0
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+struct alignas(16) SphereRec {
+    float c[3];    float r;
+    uint32_t id;   uint32_t material;  uint32_t pad0, pad1;
+};
+static_assert(sizeof(SphereRec) == 32, "SphereRec must be 32 bytes");
+
+struct alignas(16) RectRec {
+    float a0, a1, b0, b1;
+    float k;       uint32_t axis_flags;  // bits 1..0 axis, bit 8 flip-face
+    uint32_t id;   uint32_t material;
+};
+static_assert(sizeof(RectRec) == 32, "RectRec must be 32 bytes");
+
+struct alignas(16) InstRec {
+    float offset[3];   uint32_t id_base;   // ids of the instance's primitives = id_base + local id
+    float sin_t, cos_t; int32_t root;      // root node of the mesh's BVH
+    uint32_t pad0;
+    uint32_t pad1[4];
+};
+static_assert(sizeof(InstRec) == 48, "InstRec must be 48 bytes");
+
+struct alignas(16) MatRec {
+    uint32_t kind;  float r, g, b;
+    float param;    uint32_t pad0, pad1, pad2;
+};
+static_assert(sizeof(MatRec) == 32, "MatRec must be 32 bytes");
+
+struct alignas(16) LightRec {
+    uint32_t type;  float p0, p1, p2;
+    float p3, p4;   uint32_t pad0, pad1;
+};
+static_assert(sizeof(LightRec) == 32, "LightRec must be 32 bytes");
+
+// Local primitive ids inside a mesh are stored in TriRec/SphereRec/RectRec.id; the instance adds id_base.
+
+// Camera + globals passed to kernels by value.
+struct CameraRec {
+    float c0[3], c1[3], c2[3], tr[3];  // camera_to_world columns + translation
+    float origin[3];
+    float scale, aspect, time0, time1;
+};
+
+struct SceneDev {
+    const BvhNode* nodes;
+    const TriRec* tris;
+    const SphereRec* spheres;
+    const RectRec* rects;
+    const InstRec* insts;
+    const MatRec* mats;
+    const LightRec* lights;
+    uint32_t light_count;
+    int32_t root;       // root node of the top-level BVH
+    uint32_t has_instances;
+    uint32_t pad;
+    CameraRec cam;
+    float background[3];
+    float t_min;
+    uint32_t max_depth;
+    uint32_t seed;
+};
+
+// Per-lane traversal stack entries (LDS).  One inner-node step pushes at most one entry, so the stack never
+// holds more than (tree depth) entries plus the bottom marker and, for instanced scenes, one exit marker;
+// the builder bounds the combined depth of top level + bottom level to MAX_TREE_DEPTH.
+static constexpr int STACK_DEPTH = 32;
+static constexpr uint32_t MAX_TREE_DEPTH = 29;
+
+}  // namespace rrt
+#endif

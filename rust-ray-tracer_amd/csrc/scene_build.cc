@@ -1,0 +1,301 @@
+// scene_build.cc -- scene description -> primitive records with reference bounding boxes -> flat BVH.
+#include "scene_build.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#include "bvh_builder.h"
+
+namespace rrt {
+namespace {
+
+struct Expander {
+    const rrt_scene_desc* d;
+    HostScene* hs;
+    std::vector<TriRec> tri_src;  // triangle records in submission order; reordered into leaf order at the end
+    float pad = 0.f;              // conservative extra padding of every box
+    std::string* err;
+
+    bool fail(const std::string& m) {
+        *err = m;
+        return false;
+    }
+
+    // reference src/geometry/triangle.rs:82-94
+    static void tri_box(const rrt_triangle& t, float* mn, float* mx) {
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = std::min(t.v0[a], std::min(t.v1[a], t.v2[a])) - 0.0001f;
+            mx[a] = std::max(t.v0[a], std::max(t.v1[a], t.v2[a])) + 0.0001f;
+        }
+    }
+    void widen(BuildPrim& p) const {
+        for (int a = 0; a < 3; ++a) { p.bmin[a] -= pad; p.bmax[a] += pad; }
+    }
+
+    bool add_rect(const rrt_rect& r, uint32_t id, std::vector<BuildPrim>& prims) {
+        if (r.axis > 2u) return fail("rect axis must be 0, 1 or 2");
+        if (r.material >= d->material_count) return fail("rect material index out of range");
+        RectRec rec;
+        rec.a0 = r.a0; rec.a1 = r.a1; rec.b0 = r.b0; rec.b1 = r.b1; rec.k = r.k;
+        rec.axis_flags = r.axis | ((r.flags & RRT_RECT_FLIP_FACE) ? 0x100u : 0u);
+        rec.id = id;
+        rec.material = r.material;
+        BuildPrim p;
+        // reference src/geometry/aarect.rs:60-66,115-121,191-197
+        const uint32_t ia = r.axis == 0 ? 1u : 0u, ib = r.axis == 2 ? 1u : 2u;
+        p.bmin[r.axis] = r.k - 0.0001f; p.bmax[r.axis] = r.k + 0.0001f;
+        p.bmin[ia] = std::min(r.a0, r.a1); p.bmax[ia] = std::max(r.a0, r.a1);
+        p.bmin[ib] = std::min(r.b0, r.b1); p.bmax[ib] = std::max(r.b0, r.b1);
+        p.kind = KIND_RECT;
+        p.index = (uint32_t)hs->rects.size();
+        widen(p);
+        hs->rects.push_back(rec);
+        prims.push_back(p);
+        return true;
+    }
+
+    // Appends the primitives of `objs` to `prims`; ids start at `id` and advance.  mesh_info: per mesh
+    // {root node, primitive count, root box} for instances (top level only).
+    struct MeshInfo {
+        int32_t root;
+        uint32_t prim_count;
+        uint32_t depth;
+        float mn[3], mx[3];
+    };
+    bool expand(const rrt_object* objs, uint32_t n_objs, uint32_t& id, std::vector<BuildPrim>& prims,
+                const std::vector<MeshInfo>* meshes) {
+        for (uint32_t oi = 0; oi < n_objs; ++oi) {
+            const rrt_object& ob = objs[oi];
+            switch (ob.type) {
+                case RRT_OBJ_TRIANGLES: {
+                    if ((uint64_t)ob.first + ob.count > d->triangle_count) return fail("triangle run out of range");
+                    for (uint32_t i = 0; i < ob.count; ++i) {
+                        const rrt_triangle& t = d->triangles[ob.first + i];
+                        if (t.material >= d->material_count) return fail("triangle material index out of range");
+                        TriRec rec;
+                        for (int a = 0; a < 3; ++a) {
+                            rec.v0[a] = t.v0[a];
+                            rec.e1[a] = t.v1[a] - t.v0[a];  // triangle.rs:28-29
+                            rec.e2[a] = t.v2[a] - t.v0[a];
+                        }
+                        rec.id = id++;
+                        rec.material = t.material;
+                        rec.pad = 0;
+                        BuildPrim p;
+                        tri_box(t, p.bmin, p.bmax);
+                        p.kind = KIND_TRI;
+                        p.index = (uint32_t)tri_src.size();
+                        widen(p);
+                        tri_src.push_back(rec);
+                        prims.push_back(p);
+                    }
+                    break;
+                }
+                case RRT_OBJ_SPHERES: {
+                    if ((uint64_t)ob.first + ob.count > d->sphere_count) return fail("sphere run out of range");
+                    for (uint32_t i = 0; i < ob.count; ++i) {
+                        const rrt_sphere& s = d->spheres[ob.first + i];
+                        if (s.material >= d->material_count) return fail("sphere material index out of range");
+                        SphereRec rec;
+                        std::memset(&rec, 0, sizeof rec);
+                        for (int a = 0; a < 3; ++a) rec.c[a] = s.center[a];
+                        rec.r = s.radius;
+                        rec.id = id++;
+                        rec.material = s.material;
+                        BuildPrim p;
+                        const float ar = std::fabs(s.radius);
+                        for (int a = 0; a < 3; ++a) {  // sphere.rs:128-133
+                            p.bmin[a] = s.center[a] - ar;
+                            p.bmax[a] = s.center[a] + ar;
+                        }
+                        p.kind = KIND_SPHERE;
+                        p.index = (uint32_t)hs->spheres.size();
+                        widen(p);
+                        hs->spheres.push_back(rec);
+                        prims.push_back(p);
+                    }
+                    break;
+                }
+                case RRT_OBJ_RECTS: {
+                    if ((uint64_t)ob.first + ob.count > d->rect_count) return fail("rect run out of range");
+                    for (uint32_t i = 0; i < ob.count; ++i)
+                        if (!add_rect(d->rects[ob.first + i], id++, prims)) return false;
+                    break;
+                }
+                case RRT_OBJ_CUBOIDS: {
+                    if ((uint64_t)ob.first + ob.count > d->cuboid_count) return fail("cuboid run out of range");
+                    for (uint32_t i = 0; i < ob.count; ++i) {
+                        const rrt_cuboid& c = d->cuboids[ob.first + i];
+                        // the six sides in the order of reference src/geometry/cuboid.rs:24-73
+                        const rrt_rect sides[6] = {
+                            {2u, c.min[0], c.max[0], c.min[1], c.max[1], c.max[2], c.material, 0u},
+                            {2u, c.min[0], c.max[0], c.min[1], c.max[1], c.min[2], c.material, 0u},
+                            {1u, c.min[0], c.max[0], c.min[2], c.max[2], c.max[1], c.material, 0u},
+                            {1u, c.min[0], c.max[0], c.min[2], c.max[2], c.min[1], c.material, 0u},
+                            {0u, c.min[1], c.max[1], c.min[2], c.max[2], c.max[0], c.material, 0u},
+                            {0u, c.min[1], c.max[1], c.min[2], c.max[2], c.min[0], c.material, 0u},
+                        };
+                        for (int k = 0; k < 6; ++k)
+                            if (!add_rect(sides[k], id++, prims)) return false;
+                    }
+                    break;
+                }
+                case RRT_OBJ_INSTANCE: {
+                    if (!meshes) return fail("a mesh may not contain instances");
+                    if (ob.count != 1u) return fail("instance objects must have count 1");
+                    if (ob.first >= d->instance_count) return fail("instance index out of range");
+                    const rrt_instance& in = d->instances[ob.first];
+                    if (in.mesh >= d->mesh_count) return fail("instance mesh index out of range");
+                    const MeshInfo& mi = (*meshes)[in.mesh];
+                    InstRec rec;
+                    std::memset(&rec, 0, sizeof rec);
+                    for (int a = 0; a < 3; ++a) rec.offset[a] = in.offset[a];
+                    rec.sin_t = in.sin_theta;
+                    rec.cos_t = in.cos_theta;
+                    rec.root = mi.root;
+                    rec.id_base = id;
+                    id += mi.prim_count;
+                    BuildPrim p;
+                    for (int a = 0; a < 3; ++a) { p.bmin[a] = FLT_MAX; p.bmax[a] = -FLT_MAX; }
+                    for (int c = 0; c < 8; ++c) {  // world box of the rotated + translated mesh box
+                        const float x = (c & 1) ? mi.mx[0] : mi.mn[0];
+                        const float y = (c & 2) ? mi.mx[1] : mi.mn[1];
+                        const float z = (c & 4) ? mi.mx[2] : mi.mn[2];
+                        const float q[3] = {in.cos_theta * x + in.sin_theta * z + in.offset[0], y + in.offset[1],
+                                            -in.sin_theta * x + in.cos_theta * z + in.offset[2]};
+                        for (int a = 0; a < 3; ++a) { p.bmin[a] = std::min(p.bmin[a], q[a]); p.bmax[a] = std::max(p.bmax[a], q[a]); }
+                    }
+                    p.kind = KIND_INST;
+                    p.index = (uint32_t)hs->insts.size();
+                    widen(p);
+                    widen(p);
+                    hs->insts.push_back(rec);
+                    prims.push_back(p);
+                    break;
+                }
+                default:
+                    return fail("unknown object type");
+            }
+        }
+        return true;
+    }
+};
+
+static float max_abs3(const float* v) { return std::max(std::fabs(v[0]), std::max(std::fabs(v[1]), std::fabs(v[2]))); }
+
+}  // namespace
+
+rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string& err, unsigned threads) {
+    hs = HostScene();
+    if (!d) { err = "scene is NULL"; return RRT_ERR_INVALID; }
+    if (d->material_count == 0 || !d->materials) { err = "scene has no materials"; return RRT_ERR_INVALID; }
+    if ((d->triangle_count && !d->triangles) || (d->sphere_count && !d->spheres) || (d->rect_count && !d->rects) ||
+        (d->cuboid_count && !d->cuboids) || (d->instance_count && !d->instances) || (d->mesh_count && !d->meshes) ||
+        (d->mesh_object_count && !d->mesh_objects) || (d->world_count && !d->world) || (d->light_count && !d->lights)) {
+        err = "scene array pointer is NULL with a non-zero count";
+        return RRT_ERR_INVALID;
+    }
+
+    // scene scale -> conservative padding of every bounding box (beyond the reference's own 1e-4 pads)
+    float scale = max_abs3(d->camera.origin);
+    for (uint32_t i = 0; i < d->triangle_count; ++i) {
+        const rrt_triangle& t = d->triangles[i];
+        scale = std::max(scale, std::max(max_abs3(t.v0), std::max(max_abs3(t.v1), max_abs3(t.v2))));
+    }
+    for (uint32_t i = 0; i < d->sphere_count; ++i) scale = std::max(scale, max_abs3(d->spheres[i].center) + std::fabs(d->spheres[i].radius));
+    for (uint32_t i = 0; i < d->rect_count; ++i) {
+        const rrt_rect& r = d->rects[i];
+        const float v[5] = {r.a0, r.a1, r.b0, r.b1, r.k};
+        for (float f : v) scale = std::max(scale, std::fabs(f));
+    }
+    for (uint32_t i = 0; i < d->cuboid_count; ++i) scale = std::max(scale, std::max(max_abs3(d->cuboids[i].min), max_abs3(d->cuboids[i].max)));
+    float inst_scale = 0.f;
+    for (uint32_t i = 0; i < d->instance_count; ++i) inst_scale = std::max(inst_scale, max_abs3(d->instances[i].offset));
+    scale = scale * 1.5f + inst_scale;
+    if (!(scale < 1e30f)) { err = "scene coordinates are not finite"; return RRT_ERR_INVALID; }
+
+    Expander ex;
+    ex.d = d;
+    ex.hs = &hs;
+    ex.err = &err;
+    ex.pad = scale * (1.0f / 131072.0f);  // 2^-17 relative to the scene's extent
+
+    for (uint32_t i = 0; i < d->material_count; ++i) {
+        const rrt_material& m = d->materials[i];
+        if (m.kind > 3u) { err = "unknown material kind"; return RRT_ERR_INVALID; }
+        MatRec r;
+        std::memset(&r, 0, sizeof r);
+        r.kind = m.kind; r.r = m.rgb[0]; r.g = m.rgb[1]; r.b = m.rgb[2]; r.param = m.param;
+        hs.mats.push_back(r);
+    }
+    for (uint32_t i = 0; i < d->light_count; ++i) {
+        const rrt_light& l = d->lights[i];
+        if (l.type > 2u) { err = "unknown light type"; return RRT_ERR_INVALID; }
+        LightRec r;
+        std::memset(&r, 0, sizeof r);
+        r.type = l.type; r.p0 = l.p[0]; r.p1 = l.p[1]; r.p2 = l.p[2]; r.p3 = l.p[3]; r.p4 = l.p[4];
+        hs.lights.push_back(r);
+    }
+
+    std::vector<uint32_t> tri_order;
+    // depth budget: bottom levels get what they need for a balanced fallback (+ slack), the top level the rest
+    uint32_t top_budget = MAX_TREE_DEPTH;
+    std::vector<Expander::MeshInfo> meshes(d->mesh_count);
+    uint32_t deepest_mesh = 0;
+    if (d->mesh_count) {
+        // first pass: primitive counts, to split the depth budget
+        uint32_t world_prims = 0;
+        for (uint32_t i = 0; i < d->world_count; ++i) world_prims += d->world[i].type == RRT_OBJ_CUBOIDS ? 6u * d->world[i].count : d->world[i].count;
+        uint32_t need_top = 0;
+        while ((1ull << need_top) < std::max(world_prims, 1u)) ++need_top;
+        need_top += 2;  // slack for the SAH to be unbalanced near the top
+        if (need_top + 6 > MAX_TREE_DEPTH) { err = "too many top-level objects for an instanced scene"; return RRT_ERR_INVALID; }
+        top_budget = need_top;
+    }
+    for (uint32_t mi = 0; mi < d->mesh_count; ++mi) {
+        const rrt_mesh& m = d->meshes[mi];
+        if ((uint64_t)m.first_object + m.object_count > d->mesh_object_count) { err = "mesh object range out of range"; return RRT_ERR_INVALID; }
+        std::vector<BuildPrim> prims;
+        uint32_t id = 0;
+        if (!ex.expand(d->mesh_objects + m.first_object, m.object_count, id, prims, nullptr)) return RRT_ERR_INVALID;
+        const uint32_t budget = MAX_TREE_DEPTH - top_budget - 1u;
+        BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), budget, threads);
+        if (br.depth > budget) { err = "mesh too large for the traversal stack of an instanced scene"; return RRT_ERR_INVALID; }
+        meshes[mi].root = br.root;
+        meshes[mi].prim_count = id;
+        meshes[mi].depth = br.depth;
+        for (int a = 0; a < 3; ++a) { meshes[mi].mn[a] = br.root_min[a]; meshes[mi].mx[a] = br.root_max[a]; }
+        if (prims.empty()) for (int a = 0; a < 3; ++a) { meshes[mi].mn[a] = 0.f; meshes[mi].mx[a] = 0.f; }
+        deepest_mesh = std::max(deepest_mesh, br.depth);
+    }
+
+    std::vector<BuildPrim> prims;
+    uint32_t id = 0;
+    if (!ex.expand(d->world, d->world_count, id, prims, &meshes)) return RRT_ERR_INVALID;
+    BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), top_budget, threads);
+    if (br.depth + (hs.insts.empty() ? 0u : deepest_mesh + 1u) > MAX_TREE_DEPTH) {
+        err = "scene too deep for the traversal stack";
+        return RRT_ERR_INVALID;
+    }
+    hs.root = br.root;
+    hs.prim_count = id;
+    hs.depth = br.depth + (hs.insts.empty() ? 0u : deepest_mesh);
+    hs.has_instances = !hs.insts.empty();
+    if (tri_order.size() > REF_OFFSET_MASK) { err = "too many triangles"; return RRT_ERR_INVALID; }
+
+    hs.tris.resize(tri_order.size());
+    for (size_t k = 0; k < tri_order.size(); ++k) hs.tris[k] = ex.tri_src[tri_order[k]];
+
+    const rrt_camera& c = d->camera;
+    for (int a = 0; a < 3; ++a) {
+        hs.cam.c0[a] = c.c2w[a]; hs.cam.c1[a] = c.c2w[3 + a]; hs.cam.c2[a] = c.c2w[6 + a]; hs.cam.tr[a] = c.c2w[9 + a];
+        hs.cam.origin[a] = c.origin[a];
+        hs.background[a] = d->background[a];
+    }
+    hs.cam.scale = c.scale; hs.cam.aspect = c.aspect; hs.cam.time0 = c.time0; hs.cam.time1 = c.time1;
+    return RRT_OK;
+}
+
+}  // namespace rrt
