@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--config 2|1|4] [--spp S]
+
+One *step* = one full pass of the hot path over one frame: render kernel (camera rays -> closest hit ->
+scatter -> bounce, `spp` samples per pixel), the RCCL reduce of the radiance accumulation buffers to rank 0
+when N > 1, and the tone map on rank 0.  Scene, BVH, camera and materials are resident in HBM before the
+timed region.  Multi-GPU: one process per GPU; rank g renders sample indices [g*spp, (g+1)*spp) of every
+pixel (weak scaling: per-GPU work is fixed, the image gets N*spp samples).
+
+Prints ONE JSON line (rank 0): metric Mrays/s over the whole job, plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import rrt_pkg  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+NODE_BYTES, PRIM_BYTES, ACCUM_BYTES_PER_SAMPLE_AT_SPP1 = 64, 48, 12
+
+
+def build_scene(rrt, config: int):
+    """Returns (scene, width, height, default spp per GPU, workload name)."""
+    from rust_ray_tracer_amd import scenes  # noqa: F401  (registered by rrt_pkg.load())
+
+    assets = os.path.join(ROOT, "assets")
+    if config == 1:
+        s = rrt.Scene.from_gltf_file(os.path.join(assets, "default.gltf"), os.path.join(assets, "suzanne.gltf"))
+        h = 400
+        return s, rrt.image_width(h, s.camera.aspect_ratio), h, 64, "assets/default.gltf, 711x400, 64 spp"
+    if config == 2:
+        s = rrt.Scene.from_gltf_file(os.path.join(assets, "suzanne.gltf"), os.path.join(assets, "suzanne.gltf"))
+        h = 1080
+        return s, rrt.image_width(h, s.camera.aspect_ratio), h, 256, "assets/suzanne.gltf (968 tris), 1920x1080, 256 spp per GPU"
+    if config == 3:
+        s = scenes.metal_rough_spheres(rrt, assets)
+        h = 1440
+        return s, rrt.image_width(h, s.camera.aspect_ratio), h, 128, "MetalRoughSpheres (1.04M tris, extended loader), 2560x1440, 128 spp per GPU"
+    if config == 4:
+        s = scenes.synthetic_mesh(rrt, assets, subdiv=512)
+        h = 2160
+        return s, rrt.image_width(h, s.camera.aspect_ratio), h, 128, "synthetic 1,048,576-triangle displaced mesh, 3840x2160, 128 spp per GPU"
+    if config == 5:
+        s = scenes.synthetic_instanced(rrt, assets)
+        h = 4320
+        return s, rrt.image_width(h, s.camera.aspect_ratio), h, 16, "synthetic 100k-tri mesh x 100 instances, 7680x4320, 16 spp per GPU"
+    raise SystemExit(f"unknown config {config}")
+
+
+def cpu_baseline(scene, width, height, spp_full, seed, budget_s=15.0):
+    """Times the CPU restatement (reference-style pointer BVH, recursive ray_color, row-parallel threads) on a
+    bounded sample of the same workload: the full frame at a reduced number of samples per pixel."""
+    from oracle import oracle
+
+    o = oracle.OracleScene(scene)
+    threads = oracle.default_threads()
+    try:
+        o.build_ref_bvh()
+        mode = oracle.HIT_REF_BVH
+    except ValueError:
+        mode = oracle.HIT_BRUTE
+    # calibrate on a strip, then size the sample
+    strip_h = max(8, height // 32)
+    t0 = time.perf_counter()
+    _, rays = o.render(width, strip_h, 1, mode=mode, threads=threads, seed=seed)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    per_spp_full = dt * (height / strip_h)
+    spp = int(max(1, min(spp_full, budget_s / per_spp_full)))
+    t0 = time.perf_counter()
+    _, rays = o.render(width, height, spp, mode=mode, threads=threads, seed=seed)
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{width}x{height} at {spp} of {spp_full} spp ({rays} rays, {dt:.1f} s, reference-style pointer BVH)",
+            "samples_per_s": width * height * spp / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (default: the config's)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    rrt = rrt_pkg.load()
+    scene, width, height, spp, workload = build_scene(rrt, args.config)
+    if args.spp > 0:
+        spp = args.spp
+    spp_total = spp * world
+    spp_offset = rank * spp
+
+    renderer = rrt.Renderer(device=local_rank, seed=args.seed)
+    info = renderer.upload(scene)
+    accum = torch.empty((height, width, 3), dtype=torch.float32, device=device)
+    rgb8 = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
+    stream = torch.cuda.current_stream(device)
+
+    kernel_ms = []
+    rays_per_step = 0
+
+    def step(record: bool):
+        nonlocal rays_per_step
+        renderer.render_device(width, height, spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
+        st = renderer.render_stats()  # waits for the kernel; its HIP events are on `stream`
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            renderer.tonemap_device(accum.data_ptr(), width, height, spp_total, rgb8.data_ptr(), stream.cuda_stream)
+        if record:
+            kernel_ms.append(st.kernel_ms)
+            rays_per_step = st.rays
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    r = torch.tensor([float(rays_per_step)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    rays_all = float(r.item())  # rays of one step, all ranks
+
+    # --- roofline of the dominant kernel (k_render), rank 0's launch
+    roof = None
+    cpu = None
+    if rank == 0:
+        counting = rrt.Renderer(device=local_rank, seed=args.seed, count_visits=True)
+        counting.upload(scene)
+        probe_spp = min(spp, 8)
+        counting.render_device(width, height, probe_spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
+        cs = counting.render_stats()
+        counting.close()
+        nodes_per_ray = cs.node_visits / max(cs.rays, 1)
+        prims_per_ray = cs.prim_tests / max(cs.rays, 1)
+        samples = width * height * spp
+        bytes_per_ray = nodes_per_ray * NODE_BYTES + prims_per_ray * PRIM_BYTES
+        algo_bytes = rays_per_step * bytes_per_ray + width * height * 12.0
+        k_ms = float(np.mean(kernel_ms))
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None, "kernel": "k_render", "kernel_ms": k_ms, "nodes_per_ray": nodes_per_ray,
+                "prims_per_ray": prims_per_ray, "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_step,
+                "samples_per_launch": samples}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(scene, width, height, spp, args.seed)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays_all * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s (whole node)", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.config >= 4 else "reference asset (bundled glTF), random-free scene; counter-RNG seed %d" % args.seed,
+            "config": {"workload": workload, "width": width, "height": height, "spp_per_gpu": spp, "spp_total": spp_total,
+                       "max_depth": 4, "prims": info.prim_count, "bvh_nodes": info.node_count, "bvh_depth": info.bvh_depth,
+                       "scene_bytes": info.device_bytes, "bvh_build_ms": info.build_ms, "partition": "spp slices per GPU + RCCL reduce(sum) to rank 0"},
+            "samples_per_s": width * height * spp * world * args.steps / elapsed,
+            "rays_per_sample": rays_all / (width * height * spp * world),
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    renderer.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

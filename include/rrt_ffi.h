@@ -201,6 +201,10 @@ const char* rrt_last_error(const rrt_ctx* ctx);
  * and uploads it, the primitives, materials, lights and camera to HBM.                       */
 rrt_status rrt_scene_upload(rrt_ctx* ctx, const rrt_scene_desc* scene);
 rrt_status rrt_scene_get_info(const rrt_ctx* ctx, rrt_scene_info* out);
+/* Host-only dry run of the same validation + BVH build (no GPU needed, nothing uploaded): fills `out`
+ * (device_bytes = what an upload would occupy, upload_ms = 0).  Errors are reported through
+ * rrt_last_error(NULL).                                                                         */
+rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out);
 
 /* ---- closest hit on a ray batch ----  replaces: `world.hit(ray, t_min, t_max)`
  * (reference src/ray.rs:89 -> src/geometry/mod.rs:136-153) for n rays at once.               */

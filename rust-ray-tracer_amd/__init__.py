@@ -136,6 +136,7 @@ assert TRI_DTYPE.itemsize == C.sizeof(TrianglePOD)
 # every symbol include/rrt_ffi.h declares
 ABI_SYMBOLS = [
     "rrt_abi_version", "rrt_create", "rrt_destroy", "rrt_last_error", "rrt_scene_upload", "rrt_scene_get_info",
+    "rrt_scene_check",
     "rrt_intersect", "rrt_intersect_device", "rrt_render", "rrt_render_device", "rrt_render_stats", "rrt_tonemap",
     "rrt_tonemap_device", "rrt_gltf_load", "rrt_scene_free", "rrt_png_write",
 ]
@@ -160,6 +161,7 @@ def load_library() -> C.CDLL:
     lib.rrt_last_error.restype = C.c_char_p
     lib.rrt_scene_upload.argtypes = [vp, C.POINTER(SceneDescPOD)]
     lib.rrt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+    lib.rrt_scene_check.argtypes = [C.POINTER(SceneDescPOD), C.POINTER(SceneInfo)]
     lib.rrt_intersect.argtypes = [vp, vp, C.c_size_t, f32, f32, vp]
     lib.rrt_intersect_device.argtypes = [vp, vp, C.c_size_t, f32, f32, vp, vp]
     lib.rrt_render.argtypes = [vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
@@ -394,6 +396,13 @@ class Scene:
         d.background[:] = [float(x) for x in self.background]
         self._keep = keep
         return d
+
+    def check(self) -> SceneInfo:
+        """Host-only validation + BVH build (``rrt_scene_check``); works without a GPU."""
+        d = self.desc()
+        info = SceneInfo()
+        _check(load_library().rrt_scene_check(C.byref(d), C.byref(info)), None)
+        return info
 
     # -- glTF front end (reference ``Scene::from_gltf_file``, src/gltf.rs:314-351)
     @staticmethod

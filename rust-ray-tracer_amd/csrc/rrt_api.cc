@@ -33,7 +33,10 @@ struct rrt_ctx {
     // device buffers of the scene
     void* d_nodes = nullptr; void* d_tris = nullptr; void* d_spheres = nullptr; void* d_rects = nullptr;
     void* d_insts = nullptr; void* d_mats = nullptr; void* d_lights = nullptr;
-    unsigned long long* d_counters = nullptr;  // 256 B: rays, node visits, primitive tests
+    int cu_count = 1;
+    unsigned long long* d_counters = nullptr;  // 256 B: rays, node visits, primitive tests; work-queue heads at +64 B
+    float* d_partial = nullptr;                // per-chunk partial images of the last render geometry (grown on demand)
+    size_t partial_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipStream_t last_stream = nullptr;
     bool render_pending = false;
@@ -111,6 +114,7 @@ rrt_status rrt_create(const rrt_config* cfg, rrt_ctx** out) {
     rrt_ctx* c = new (std::nothrow) rrt_ctx();
     if (!c) return set_err(nullptr, RRT_ERR_OOM, "rrt_create: out of host memory");
     c->cfg = *cfg;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
     if ((e = hipSetDevice(cfg->device)) != hipSuccess || (e = hipMalloc((void**)&c->d_counters, 256)) != hipSuccess ||
         (e = hipEventCreate(&c->ev_start)) != hipSuccess || (e = hipEventCreate(&c->ev_stop)) != hipSuccess) {
         rrt_status st = hip_fail(nullptr, e, "rrt_create");
@@ -126,6 +130,7 @@ void rrt_destroy(rrt_ctx* c) {
     (void)hipSetDevice(c->cfg.device);
     free_scene(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
@@ -186,6 +191,33 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     return RRT_OK;
 }
 
+rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
+    if (!scene || !out) return set_err(nullptr, RRT_ERR_INVALID, "rrt_scene_check: NULL argument");
+    HostScene hs;
+    std::string err;
+    const auto t0 = std::chrono::steady_clock::now();
+    rrt_status st;
+    try {
+        st = build_host_scene(scene, hs, err, build_threads());
+    } catch (const std::bad_alloc&) {
+        return set_err(nullptr, RRT_ERR_OOM, "rrt_scene_check: out of host memory while building the BVH");
+    } catch (const std::exception& ex) {
+        return set_err(nullptr, RRT_ERR_INVALID, std::string("rrt_scene_check: ") + ex.what());
+    }
+    if (st != RRT_OK) return set_err(nullptr, st, "rrt_scene_check: " + err);
+    std::memset(out, 0, sizeof *out);
+    out->prim_count = hs.prim_count;
+    out->node_count = (uint32_t)hs.nodes.size();
+    out->tri_count = (uint32_t)hs.tris.size();
+    out->bvh_depth = hs.depth;
+    auto sz = [](size_t n, size_t rec) { return (uint64_t)(n ? n : 1) * rec; };
+    out->device_bytes = sz(hs.nodes.size(), sizeof(BvhNode)) + sz(hs.tris.size(), sizeof(TriRec)) + sz(hs.spheres.size(), sizeof(SphereRec)) +
+                        sz(hs.rects.size(), sizeof(RectRec)) + sz(hs.insts.size(), sizeof(InstRec)) + sz(hs.mats.size(), sizeof(MatRec)) +
+                        sz(hs.lights.size(), sizeof(LightRec));
+    out->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RRT_OK;
+}
+
 rrt_status rrt_scene_get_info(const rrt_ctx* c, rrt_scene_info* out) {
     if (!c || !out) return set_err(nullptr, RRT_ERR_INVALID, "rrt_scene_get_info: NULL argument");
     if (!c->has_scene) return set_err(const_cast<rrt_ctx*>(c), RRT_ERR_STATE, "rrt_scene_get_info: no scene uploaded");
@@ -236,9 +268,26 @@ rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32
     if ((uint64_t)spp + spp_offset > 0xFFFFFFFFull) return set_err(c, RRT_ERR_INVALID, "rrt_render_device: sample index overflows");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     hipStream_t s = (hipStream_t)stream;
+    uint32_t n_chunks = render_chunks(spp);
+    if (const char* e = std::getenv("RRT_CHUNKS")) {
+        const int v = std::atoi(e);
+        if (v >= 1) n_chunks = std::min<uint32_t>((uint32_t)v, spp);
+    }
+    while (n_chunks > 1u && (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * n_chunks > 0x7FFFFFFFull) n_chunks /= 2u;
+    const size_t need = n_chunks > 1u ? (size_t)n_chunks * width * height * 3u * sizeof(float) : 0u;
+    if (need > c->partial_bytes) {
+        // the old workspace may still be read by a render in flight on another stream
+        RRT_HIP(c, hipDeviceSynchronize());
+        if (c->d_partial) (void)hipFree(c->d_partial);
+        c->d_partial = nullptr;
+        c->partial_bytes = 0;
+        RRT_HIP(c, hipMalloc((void**)&c->d_partial, need));
+        c->partial_bytes = need;
+    }
     RRT_HIP(c, hipMemsetAsync(c->d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
-    RRT_HIP(c, launch_render(c->sdev, width, height, spp, spp_offset, d_accum, c->d_counters,
+    RRT_HIP(c, launch_render(c->sdev, width, height, spp, spp_offset, d_accum, c->d_partial, n_chunks, c->d_counters,
+                             reinterpret_cast<unsigned int*>(c->d_counters + 8), c->cu_count,
                              (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, s));
     RRT_HIP(c, hipEventRecord(c->ev_stop, s));
     c->last_stream = s;

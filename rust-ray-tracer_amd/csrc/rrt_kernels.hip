@@ -1,11 +1,13 @@
-// rrt_kernels.hip -- gfx950 kernels: path-tracing megakernel, ray-batch closest hit, tone map.
+// rrt_kernels.hip -- gfx950 kernels: persistent path-tracing megakernel, ray-batch closest hit, tone map.
 //
-// k_render: one lane owns one pixel; one 64-lane wavefront owns an 8x8 pixel tile.  A lane runs the
+// k_render is a persistent-wavefront kernel: the grid is sized to what the chip holds at once, and every
+// 64-lane wavefront pulls work items from eight queues (one per group of workgroups that share an XCD).
+// A work item is (8x8 pixel tile, chunk of samples).  Inside an item one lane owns one pixel and runs the
 // reference's per-pixel loop (src/main.rs:87-103) flattened over (sample, bounce): every loop trip
-// traces exactly one ray, and a lane whose path ended starts its next sample at once, so lanes are
-// never parked waiting for the longest path in the wave.  The radiance sum stays in registers and is
-// written once (12 bytes per pixel).  Traversal stacks live in LDS (STACK_DEPTH dwords per lane,
-// [entry][lane] so that a wave access touches 64 consecutive banks).
+// traces exactly one ray, and a lane whose path ended starts its next sample at once, so lanes are never
+// parked waiting for the longest path in the wave.  The radiance sum stays in registers and is written
+// once per item (12 bytes per pixel).  Traversal stacks live in LDS (STACK_DEPTH dwords per lane, laid
+// out [entry][thread] so that a wave access touches 64 consecutive banks).
 #include <hip/hip_runtime.h>
 
 #include "rrt_device.h"
@@ -14,89 +16,114 @@
 namespace rrt {
 
 static constexpr int WAVE = 64;
-
-// Workgroup id -> tile index such that the workgroups dealt to one XCD (ids congruent mod 8) cover a
-// contiguous range of tiles: the 4 MiB L2 of an XCD then sees one eighth of the image.  Bijective for
-// any tile count.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t n) {
-    const uint32_t q = n / 8u, r = n % 8u;
-    const uint32_t xcd = bid % 8u, idx = bid / 8u;
-    const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return base + idx;
-}
+static constexpr int RENDER_BLOCK = 256;  // 4 independent wavefronts per workgroup
+static constexpr uint32_t N_QUEUES = 8;   // workgroup ids congruent mod 8 are dealt to one XCD and share its L2
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
     return v;
 }
 
-template <bool INST, bool COUNT>
-__global__ __launch_bounds__(WAVE) void k_render(SceneDev S, uint32_t width, uint32_t height, uint32_t spp,
-                                                 uint32_t spp_offset, uint32_t tiles_x, uint32_t n_tiles,
-                                                 float* __restrict__ accum, unsigned long long* __restrict__ counters) {
-    __shared__ int s_stack[STACK_DEPTH * WAVE];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t tile = xcd_remap(blockIdx.x, n_tiles);
-    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-    const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
-    const bool inside = x < width && y < height;
-    int* stack = s_stack + lane;
+// First work item of queue q: the items are split into N_QUEUES contiguous ranges, i.e. contiguous image
+// regions, so that the 4 MiB L2 of an XCD sees one eighth of the frame.
+__device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
+    return (uint32_t)(((unsigned long long)q * n_work) / N_QUEUES);
+}
 
-    const uint32_t pixel = y * width + x;
+template <bool INST, bool COUNT>
+__global__ __launch_bounds__(RENDER_BLOCK) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+                                                         unsigned long long* __restrict__ counters,
+                                                         unsigned int* __restrict__ heads) {
+    __shared__ int s_stack[STACK_DEPTH * RENDER_BLOCK];
+    const uint32_t lane = threadIdx.x & 63u;
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t width = G.width, height = G.height;
     const V3 bg = v3(S.background[0], S.background[1], S.background[2]);
-    V3 sum = v3(0.f, 0.f, 0.f);
+
     uint32_t n_rays = 0;
     TraceCounters cnt = {0u, 0u};
+    uint32_t q = blockIdx.x % N_QUEUES;
+    uint32_t exhausted = 0;
 
-    uint32_t s = inside ? 0u : spp;  // sample counter of this lane
-    V3 o, d, beta, radiance;
-    uint32_t depth = 0;
-    Rng rng;
-    if (s < spp) {
-        rng = rng_init(S.seed, pixel, spp_offset + s);
-        const float u = (float)x + rng_f32(rng);  // main.rs:92-93
-        const float v = (float)y + rng_f32(rng);
-        rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
-        camera_ray(S.cam, u, v, width, height, o, d);
-        beta = v3(1.f, 1.f, 1.f);
-        radiance = v3(0.f, 0.f, 0.f);
-        depth = S.max_depth;
-    }
-
-    while (s < spp) {
-        Best best;
-        trace<INST, COUNT>(S, o, d, S.t_min, __builtin_inff(), stack, WAVE, best, cnt);
-        n_rays++;
-        bool alive;
-        if (best.id == 0xFFFFFFFFu) {
-            radiance = radiance + mulv(beta, bg);  // ray.rs:126
-            alive = false;
-        } else {
-            const Surface sf = surface_at(S, best, o, d);
-            alive = shade(S, sf, o, d, beta, radiance, rng);
+    for (;;) {
+        // ---- next work item: own queue first, then the others' leftovers
+        uint32_t work = 0xFFFFFFFFu;
+        while (exhausted < N_QUEUES) {
+            unsigned int ticket = 0;
+            if (lane == 0) ticket = atomicAdd(&heads[q], 1u);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            const uint32_t b = queue_begin(q, G.n_work), e = queue_begin(q + 1u, G.n_work);
+            if (ticket < e - b) {
+                work = b + ticket;
+                break;
+            }
+            q = (q + 1u) % N_QUEUES;
+            exhausted++;
         }
-        depth--;
-        if (depth == 0u) alive = false;  // ray.rs:85-87: depth 0 contributes black
-        if (!alive) {
-            sum = sum + radiance;  // main.rs:95
-            s++;
-            if (s < spp) {
-                rng = rng_init(S.seed, pixel, spp_offset + s);
-                const float u = (float)x + rng_f32(rng);
-                const float v = (float)y + rng_f32(rng);
-                rng.ctr++;
-                camera_ray(S.cam, u, v, width, height, o, d);
-                beta = v3(1.f, 1.f, 1.f);
-                radiance = v3(0.f, 0.f, 0.f);
-                depth = S.max_depth;
+        if (work == 0xFFFFFFFFu) break;  // every queue is empty: this wave is done
+
+        const uint32_t tile = work / G.n_chunks, chunk = work % G.n_chunks;
+        const uint32_t tx = tile % G.tiles_x, ty = tile / G.tiles_x;
+        const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+        const bool inside = x < width && y < height;
+        // samples [first, first + spp) of this chunk, as absolute sample indices
+        const uint32_t first = chunk * G.chunk_spp;
+        const uint32_t spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
+        const uint32_t spp_offset = G.spp_offset + first;
+        const uint32_t pixel = y * width + x;
+
+        V3 sum = v3(0.f, 0.f, 0.f);
+        uint32_t s = inside ? 0u : spp;  // sample counter of this lane
+        V3 o, d, beta, radiance;
+        uint32_t depth = 0;
+        Rng rng;
+        if (s < spp) {
+            rng = rng_init(S.seed, pixel, spp_offset + s);
+            const float u = (float)x + rng_f32(rng);  // main.rs:92-93
+            const float v = (float)y + rng_f32(rng);
+            rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
+            camera_ray(S.cam, u, v, width, height, o, d);
+            beta = v3(1.f, 1.f, 1.f);
+            radiance = v3(0.f, 0.f, 0.f);
+            depth = S.max_depth;
+        }
+
+        while (s < spp) {
+            Best best;
+            trace<INST, COUNT>(S, o, d, S.t_min, __builtin_inff(), stack, RENDER_BLOCK, best, cnt);
+            n_rays++;
+            bool alive;
+            if (best.id == 0xFFFFFFFFu) {
+                radiance = radiance + mulv(beta, bg);  // ray.rs:126
+                alive = false;
+            } else {
+                const Surface sf = surface_at(S, best, o, d);
+                alive = shade(S, sf, o, d, beta, radiance, rng);
+            }
+            depth--;
+            if (depth == 0u) alive = false;  // ray.rs:85-87: depth 0 contributes black
+            if (!alive) {
+                sum = sum + radiance;  // main.rs:95
+                s++;
+                if (s < spp) {
+                    rng = rng_init(S.seed, pixel, spp_offset + s);
+                    const float u = (float)x + rng_f32(rng);
+                    const float v = (float)y + rng_f32(rng);
+                    rng.ctr++;
+                    camera_ray(S.cam, u, v, width, height, o, d);
+                    beta = v3(1.f, 1.f, 1.f);
+                    radiance = v3(0.f, 0.f, 0.f);
+                    depth = S.max_depth;
+                }
             }
         }
+
+        if (inside) {
+            float* px = out + 3ull * ((size_t)chunk * width * height + pixel);
+            px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
+        }
     }
 
-    if (inside) {
-        float* px = accum + 3ull * pixel;
-        px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
-    }
     const unsigned long long rays = wave_sum((unsigned long long)n_rays);
     if (COUNT) {
         const unsigned long long nn = wave_sum((unsigned long long)cnt.nodes);
@@ -167,22 +194,65 @@ __global__ void k_tonemap(const float* __restrict__ accum, uint32_t width, uint3
     }
 }
 
+// Sums the per-chunk partial images in chunk order (deterministic, unlike float atomics).
+__global__ void k_reduce_chunks(const float* __restrict__ partial, uint32_t n_floats, uint32_t n_chunks,
+                                float* __restrict__ accum) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats) return;
+    float s = 0.0f;
+    for (uint32_t c = 0; c < n_chunks; ++c) s += partial[(size_t)c * n_floats + i];
+    accum[i] = s;
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 
+uint32_t render_chunks(uint32_t spp) {
+    // at least 4 samples per chunk, at most 32 chunks
+    uint32_t n = spp / 4u;
+    if (n < 1u) n = 1u;
+    if (n > 32u) n = 32u;
+    return n;
+}
+
+template <bool INST, bool COUNT>
+static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, float* out, unsigned long long* d_counters,
+                                        unsigned int* d_heads, int cu_count, hipStream_t stream) {
+    // persistent grid: as many workgroups as the chip holds at once (never more than there are work items)
+    static int blocks_per_cu = 0;  // per template instantiation
+    if (blocks_per_cu == 0) {
+        int n = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<INST, COUNT>, RENDER_BLOCK, 0);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = n > 0 ? n : 1;
+    }
+    unsigned long long blocks = (unsigned long long)blocks_per_cu * (unsigned)cu_count;
+    const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;
+    if (blocks > needed) blocks = needed;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL((k_render<INST, COUNT>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
-                         float* d_accum, unsigned long long* d_counters, bool count_visits, hipStream_t stream) {
-    const uint32_t tiles_x = (width + 7u) / 8u, tiles_y = (height + 7u) / 8u;
-    const uint32_t n_tiles = tiles_x * tiles_y;
-    dim3 grid(n_tiles), block(WAVE);
+                         float* d_accum, float* d_partial, uint32_t n_chunks, unsigned long long* d_counters,
+                         unsigned int* d_heads, int cu_count, bool count_visits, hipStream_t stream) {
+    RenderGeom G;
+    G.width = width; G.height = height; G.spp = spp; G.spp_offset = spp_offset;
+    G.tiles_x = (width + 7u) / 8u;
+    G.n_tiles = G.tiles_x * ((height + 7u) / 8u);
+    G.n_chunks = n_chunks;
+    G.chunk_spp = (spp + n_chunks - 1u) / n_chunks;
+    G.n_work = G.n_tiles * G.n_chunks;
+    float* out = n_chunks > 1u ? d_partial : d_accum;
     const bool inst = S.has_instances != 0u;
-    if (inst && count_visits)
-        hipLaunchKernelGGL((k_render<true, true>), grid, block, 0, stream, S, width, height, spp, spp_offset, tiles_x, n_tiles, d_accum, d_counters);
-    else if (inst)
-        hipLaunchKernelGGL((k_render<true, false>), grid, block, 0, stream, S, width, height, spp, spp_offset, tiles_x, n_tiles, d_accum, d_counters);
-    else if (count_visits)
-        hipLaunchKernelGGL((k_render<false, true>), grid, block, 0, stream, S, width, height, spp, spp_offset, tiles_x, n_tiles, d_accum, d_counters);
-    else
-        hipLaunchKernelGGL((k_render<false, false>), grid, block, 0, stream, S, width, height, spp, spp_offset, tiles_x, n_tiles, d_accum, d_counters);
+    hipError_t e;
+    if (inst && count_visits) e = launch_render_variant<true, true>(S, G, out, d_counters, d_heads, cu_count, stream);
+    else if (inst) e = launch_render_variant<true, false>(S, G, out, d_counters, d_heads, cu_count, stream);
+    else if (count_visits) e = launch_render_variant<false, true>(S, G, out, d_counters, d_heads, cu_count, stream);
+    else e = launch_render_variant<false, false>(S, G, out, d_counters, d_heads, cu_count, stream);
+    if (e != hipSuccess || n_chunks <= 1u) return e;
+    const uint32_t n_floats = width * height * 3u;
+    hipLaunchKernelGGL(k_reduce_chunks, dim3((n_floats + 255u) / 256u), dim3(256), 0, stream, d_partial, n_floats, n_chunks, d_accum);
     return hipGetLastError();
 }
 

@@ -113,6 +113,15 @@ struct SceneDev {
     uint32_t seed;
 };
 
+// Launch geometry of the render kernel.  The frame is cut into 8x8 pixel tiles and the sample range into
+// `n_chunks` chunks of `chunk_spp` samples; one work item = (tile, chunk), item index = tile * n_chunks + chunk,
+// so that the chunks of an expensive tile are handed out back to back and run on many CUs at the same time.
+struct RenderGeom {
+    uint32_t width, height, spp, spp_offset;
+    uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;
+    uint32_t n_work;
+};
+
 // Per-lane traversal stack entries (LDS).  One inner-node step pushes at most one entry, so the stack never
 // holds more than (tree depth) entries plus the bottom marker and, for instanced scenes, one exit marker;
 // the builder bounds the combined depth of top level + bottom level to MAX_TREE_DEPTH.
