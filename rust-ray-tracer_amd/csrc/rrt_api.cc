@@ -268,7 +268,7 @@ rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32
     if ((uint64_t)spp + spp_offset > 0xFFFFFFFFull) return set_err(c, RRT_ERR_INVALID, "rrt_render_device: sample index overflows");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    uint32_t n_chunks = render_chunks(spp);
+    uint32_t n_chunks = render_chunks(width, height, spp);
     if (const char* e = std::getenv("RRT_CHUNKS")) {
         const int v = std::atoi(e);
         if (v >= 1) n_chunks = std::min<uint32_t>((uint32_t)v, spp);

@@ -224,12 +224,19 @@ __device__ __forceinline__ void to_object_space(const InstRec& in, V3 o, V3 d, V
 
 // ---------------------------------------------------------------------------------------------
 // BVH traversal: closest hit = min (t, id) over the reference's per-primitive tests.
-// The slab test is conservative: t values carry at most 3 roundings (subtract, multiply, and the
-// reciprocal), covered by widening the far side by 2^-21 relative (Ize, "Robust BVH Ray Traversal").
+// The slab test is conservative: each t carries the rounding of the subtraction and of the multiplication
+// (half an ulp each) plus the 1-ulp error of v_rcp_f32, i.e. at most 2 ulp on the near and on the far
+// side; widening the far side by 1e-6 relative (8 ulp) covers both (Ize, "Robust BVH Ray Traversal").
 // NaN slabs (0 * inf) drop out of min/max and count as hits, like f32::max/min in the reference's
 // src/bvh/aabb.rs:24-28.
 // `stack` points at this lane's slot of the LDS stack; entries are `stride` ints apart.
 // ---------------------------------------------------------------------------------------------
+// Reciprocal direction for the slab test only (never used by a primitive test): the hardware
+// approximation is enough because the comparison below carries its own error margin.
+__device__ __forceinline__ V3 slab_reciprocal(V3 d) {
+    return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+}
+
 struct TraceCounters {
     uint32_t nodes, prims;
 };
@@ -238,10 +245,10 @@ template <bool INST, bool COUNT>
 __device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin, float tmax, int* stack, int stride,
                                       Best& best, TraceCounters& cnt) {
     best.t = tmax; best.id = 0xFFFFFFFFu; best.u = 0.f; best.v = 0.f; best.what = 0u; best.inst = -1;
-    const float far_scale = 1.0000005f;
+    const float far_scale = 1.000001f;
 
     V3 ro = o, rd = d;  // ray in the space being traversed (world, or an instance's object space)
-    V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+    V3 inv = slab_reciprocal(rd);
     uint32_t id_base = 0;
     int32_t cur_inst = -1;
 
@@ -307,7 +314,7 @@ __device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin,
         } else if (INST && kind == KIND_INST) {
             const InstRec in = S.insts[first];
             to_object_space(in, o, d, ro, rd);
-            inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            inv = slab_reciprocal(rd);
             id_base = in.id_base;
             cur_inst = (int32_t)first;
             stack[sp * stride] = REF_INST_EXIT;
@@ -316,7 +323,7 @@ __device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin,
             continue;
         } else if (INST && kind == KIND_INST_EXIT) {
             ro = o; rd = d;
-            inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+            inv = slab_reciprocal(rd);
             id_base = 0;
             cur_inst = -1;
         }

@@ -10,7 +10,7 @@
 namespace rrt {
 
 // Number of sample chunks a frame of `spp` samples per pixel is cut into (work item = tile x chunk).
-uint32_t render_chunks(uint32_t spp);
+uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp);
 
 // d_counters: 3 x u64 in device memory {rays, node visits, primitive tests}; the kernel ADDS to them.
 // d_heads:    N_QUEUES (8) x u32 work-queue heads, zero before the launch.

@@ -44,23 +44,27 @@ __global__ __launch_bounds__(RENDER_BLOCK) void k_render(SceneDev S, RenderGeom 
     TraceCounters cnt = {0u, 0u};
     uint32_t q = blockIdx.x % N_QUEUES;
     uint32_t exhausted = 0;
+    // A ticket is always drawn one item ahead, so that the round trip of the atomic overlaps the rendering
+    // of the current item.  Every drawn ticket is resolved by the wave that drew it before that wave exits.
+    unsigned int drawn = 0;
+    if (lane == 0) drawn = atomicAdd(&heads[q], 1u);
 
     for (;;) {
         // ---- next work item: own queue first, then the others' leftovers
         uint32_t work = 0xFFFFFFFFu;
-        while (exhausted < N_QUEUES) {
-            unsigned int ticket = 0;
-            if (lane == 0) ticket = atomicAdd(&heads[q], 1u);
-            ticket = __builtin_amdgcn_readfirstlane(ticket);
+        for (;;) {
+            const unsigned int ticket = __builtin_amdgcn_readfirstlane(drawn);
             const uint32_t b = queue_begin(q, G.n_work), e = queue_begin(q + 1u, G.n_work);
             if (ticket < e - b) {
                 work = b + ticket;
                 break;
             }
             q = (q + 1u) % N_QUEUES;
-            exhausted++;
+            if (++exhausted >= N_QUEUES) break;
+            if (lane == 0) drawn = atomicAdd(&heads[q], 1u);
         }
         if (work == 0xFFFFFFFFu) break;  // every queue is empty: this wave is done
+        if (lane == 0) drawn = atomicAdd(&heads[q], 1u);
 
         const uint32_t tile = work / G.n_chunks, chunk = work % G.n_chunks;
         const uint32_t tx = tile % G.tiles_x, ty = tile / G.tiles_x;
@@ -206,12 +210,19 @@ __global__ void k_reduce_chunks(const float* __restrict__ partial, uint32_t n_fl
 
 // ---- launchers --------------------------------------------------------------------------------
 
-uint32_t render_chunks(uint32_t spp) {
-    // at least 4 samples per chunk, at most 32 chunks
-    uint32_t n = spp / 4u;
-    if (n < 1u) n = 1u;
+uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp) {
+    // Measured on MI355X: about 16 samples per item amortise the queue ticket and the 12-byte-per-pixel
+    // write of an item; small frames get more, smaller items so that every resident wave finds a few
+    // (target: 4 items per wavefront slot of the chip, 256 CUs x 20 wavefronts).  Never fewer than 4
+    // samples per item, never more than 32 partial images.
+    const uint64_t n_tiles = (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u);
+    uint64_t n = (spp + 15u) / 16u;
+    const uint64_t for_balance = (4ull * 256ull * 20ull + n_tiles - 1u) / n_tiles;
+    if (n < for_balance) n = for_balance;
+    if (n > spp / 4u) n = spp / 4u;
     if (n > 32u) n = 32u;
-    return n;
+    if (n < 1u) n = 1u;
+    return (uint32_t)n;
 }
 
 template <bool INST, bool COUNT>

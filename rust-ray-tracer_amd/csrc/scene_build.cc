@@ -183,7 +183,15 @@ struct Expander {
     }
 };
 
-static float max_abs3(const float* v) { return std::max(std::fabs(v[0]), std::max(std::fabs(v[1]), std::fabs(v[2]))); }
+// max |v[i]|, or +inf as soon as a component is not finite (std::max alone would skip a NaN)
+static float max_abs3(const float* v) {
+    float m = 0.f;
+    for (int i = 0; i < 3; ++i) {
+        if (!std::isfinite(v[i])) return INFINITY;
+        m = std::max(m, std::fabs(v[i]));
+    }
+    return m;
+}
 
 }  // namespace
 
@@ -204,11 +212,14 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         const rrt_triangle& t = d->triangles[i];
         scale = std::max(scale, std::max(max_abs3(t.v0), std::max(max_abs3(t.v1), max_abs3(t.v2))));
     }
-    for (uint32_t i = 0; i < d->sphere_count; ++i) scale = std::max(scale, max_abs3(d->spheres[i].center) + std::fabs(d->spheres[i].radius));
+    for (uint32_t i = 0; i < d->sphere_count; ++i) {
+        if (!std::isfinite(d->spheres[i].radius)) scale = INFINITY;
+        scale = std::max(scale, max_abs3(d->spheres[i].center) + std::fabs(d->spheres[i].radius));
+    }
     for (uint32_t i = 0; i < d->rect_count; ++i) {
         const rrt_rect& r = d->rects[i];
         const float v[5] = {r.a0, r.a1, r.b0, r.b1, r.k};
-        for (float f : v) scale = std::max(scale, std::fabs(f));
+        for (float f : v) scale = std::isfinite(f) ? std::max(scale, std::fabs(f)) : INFINITY;
     }
     for (uint32_t i = 0; i < d->cuboid_count; ++i) scale = std::max(scale, std::max(max_abs3(d->cuboids[i].min), max_abs3(d->cuboids[i].max)));
     float inst_scale = 0.f;

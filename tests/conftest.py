@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def rrt():
+    import rrt_pkg
+
+    return rrt_pkg.load()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+
+    o.load()
+    return o
+
+
+@pytest.fixture(scope="session")
+def assets():
+    return os.path.join(ROOT, "assets")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")

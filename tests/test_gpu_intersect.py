@@ -1,0 +1,160 @@
+"""Parity gate 1: closest hit of the HIP path (through the C ABI, rrt_intersect) against the CPU oracle and the committed
+golden vectors.  Primitive ids bit-exact, t within 1e-5 relative (north star), u and v within 1e-5 absolute."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+SCENE_NAMES = ["default", "suzanne", "mixed", "instanced", "cornell", "synthetic"]
+
+
+@pytest.fixture(scope="module")
+def renderer_cache(rrt):
+    cache = {}
+    yield cache
+    for r, _ in cache.values():
+        r.close()
+
+
+def get(rrt, cache, name):
+    if name not in cache:
+        scene = helpers.SCENES[name](rrt)
+        r = rrt.Renderer(device=0, seed=1)
+        r.upload(scene)
+        cache[name] = (r, scene)
+    return cache[name]
+
+
+@pytest.mark.parametrize("name", SCENE_NAMES)
+def test_ray_classes_match_the_oracle(rrt, oracle, renderer_cache, name):
+    r, scene = get(rrt, renderer_cache, name)
+    o = oracle.OracleScene(scene)
+    suite = helpers.ray_suite(scene, o, n=2048, seed=33)
+    for kind, rays in suite.items():
+        got, want = r.intersect(rays), o.intersect(rays)
+        helpers.assert_hits_match(got, want)
+        if kind == "primary" and name != "default":
+            assert (want["prim_id"] >= 0).mean() > 0.05, "the batch should hit something"
+
+
+@pytest.mark.parametrize("name", ["default", "suzanne", "mixed", "instanced", "cornell"])
+def test_golden_vectors(rrt, renderer_cache, golden_dir, name):
+    r, _ = get(rrt, renderer_cache, name)
+    g = np.load(os.path.join(golden_dir, f"rays_{name}.npz"))
+    for kind in ("primary", "bounce", "adversarial"):
+        helpers.assert_hits_match(r.intersect(g[f"{kind}_rays"]), g[f"{kind}_hits"])
+
+
+def test_t_range_arguments(rrt, oracle, renderer_cache):
+    r, scene = get(rrt, renderer_cache, "mixed")
+    o = oracle.OracleScene(scene)
+    rays = helpers.primary_rays(o, 160, 90, 1024, seed=2)
+    for t_min, t_max in ((1e-4, 8.0), (7.0, 9.5), (0.0, float("inf")), (10.0, 10.0)):
+        helpers.assert_hits_match(r.intersect(rays, t_min=t_min, t_max=t_max), o.intersect(rays, t_min=t_min, t_max=t_max))
+
+
+def test_ties_resolve_to_the_lowest_id(rrt, oracle):
+    s = rrt.Scene()
+    m = s.add_material(rrt.Lambertian(0.5, 0.5, 0.5))
+    tri = np.array([[(0, 0, 0), (1, 0, 0), (0, 1, 0)]], np.float32)
+    s.add_triangles(np.repeat(tri, 37, axis=0), m)  # coincident triangles in several leaves
+    s.add_rect(2, -1, 1, -1, 1, 0.0, m)             # and a rectangle in the same plane (id 37)
+    r = rrt.Renderer()
+    r.upload(s)
+    g = np.random.default_rng(0)
+    p = g.uniform(0.05, 0.45, size=(256, 2)).astype(np.float32)
+    rays = helpers.make_rays(np.concatenate([p, np.ones((256, 1), np.float32)], 1), np.tile(np.float32([0, 0, -1]), (256, 1)))
+    got = r.intersect(rays)
+    assert np.all(got["prim_id"] == 0) and np.all(got["t"] == 1.0)
+    helpers.assert_hits_match(got, oracle.OracleScene(s).intersect(rays))
+    r.close()
+
+
+def test_empty_and_ragged_batches(rrt, oracle, renderer_cache):
+    r, scene = get(rrt, renderer_cache, "default")
+    o = oracle.OracleScene(scene)
+    assert len(r.intersect(np.zeros(0, rrt.RAY_DTYPE))) == 0
+    for n in (1, 63, 64, 65, 1000):
+        rays = helpers.primary_rays(o, 71, 40, n, seed=n)
+        helpers.assert_hits_match(r.intersect(rays), o.intersect(rays))
+    # degenerate rays: zero direction, NaN direction, infinite origin -> misses, never a fault
+    bad = helpers.make_rays([(0, 0, 5), (0, 0, 5), (np.inf, 0, 0), (0, 0, 5)], [(0, 0, 0), (np.nan, 0, -1), (0, 0, -1), (0, 0, -np.inf)])
+    got, want = r.intersect(bad), o.intersect(bad)
+    assert np.array_equal(got["prim_id"], want["prim_id"])
+
+
+def test_empty_scene_and_single_primitive(rrt, oracle):
+    s = rrt.Scene()
+    m = s.add_material(rrt.Lambertian(0.5, 0.5, 0.5))
+    r = rrt.Renderer()
+    r.upload(s)
+    rays = helpers.make_rays([(0, 0, 5)] * 3, [(0, 0, -1), (1, 0, 0), (0, 1, 0)])
+    assert np.all(r.intersect(rays)["prim_id"] == -1)
+    s.add_sphere((0, 0, 0), 1.0, m)
+    r.upload(s)  # re-upload replaces the scene
+    got = r.intersect(rays)
+    assert got["prim_id"][0] == 0 and got["t"][0] == 4.0 and got["prim_id"][1] == -1
+    helpers.assert_hits_match(got, oracle.OracleScene(s).intersect(rays))
+    r.close()
+
+
+def test_large_mesh_random_rays_match_exhaustive_search(rrt, oracle):
+    """Full-size geometry (the 1,048,576-triangle benchmark mesh): a random subset of rays against brute force, and
+    size-independent properties on a large batch."""
+    from rust_ray_tracer_amd import scenes
+
+    scene = scenes.synthetic_mesh(rrt, helpers.ASSETS, subdiv=512)
+    assert scene.triangle_count == 1048576
+    r = rrt.Renderer()
+    info = r.upload(scene)
+    assert info.prim_count == 1048577
+    o = oracle.OracleScene(scene)
+    big = helpers.primary_rays(o, 3840, 2160, 1 << 20, seed=77)
+    got = r.intersect(big)
+    hit = got["prim_id"] >= 0
+    assert 0.3 < hit.mean() <= 1.0
+    assert np.all(got["t"][hit] >= 1e-4) and np.all(np.isfinite(got["t"][hit]))
+    assert np.all((got["u"][hit] >= 0) & (got["u"][hit] <= 1) & (got["v"][hit] >= 0) & (got["u"][hit] + got["v"][hit] <= 1.0 + 1e-6) | (got["prim_id"][hit] == 1048576))
+    assert np.array_equal(got, r.intersect(big))  # deterministic
+    # shrinking t_max to the found t still finds the same primitive (inclusive upper bound), shrinking below loses it
+    sub = np.nonzero(hit)[0][:4096]
+    again = r.intersect(big[sub], t_max=float(got["t"][sub].max()))
+    assert np.array_equal(again["prim_id"], got["prim_id"][sub])
+    # exhaustive oracle on a subset (1M triangles x 1536 rays)
+    pick = np.random.default_rng(3).choice(len(big), 1024, replace=False)
+    bounce = helpers.bounce_rays(o, big[pick[:512]], seed=5)
+    sample = np.concatenate([big[pick], bounce])
+    helpers.assert_hits_match(r.intersect(sample), o.intersect(sample))
+    r.close()
+
+
+def test_api_errors(rrt):
+    r = rrt.Renderer()
+    with pytest.raises(rrt.RrtError) as e:
+        r.intersect(np.zeros(4, rrt.RAY_DTYPE))
+    assert e.value.status == 7  # RRT_ERR_STATE: no scene uploaded
+    with pytest.raises(rrt.RrtError) as e:
+        r.render(8, 8, 1)
+    assert e.value.status == 7
+    s = rrt.Scene()
+    s.add_material(rrt.Lambertian(0.5, 0.5, 0.5))
+    s.add_sphere((0, 0, 0), 1.0, 0)
+    r.upload(s)
+    for w, h, spp in ((0, 8, 1), (8, 0, 1), (8, 8, 0)):
+        with pytest.raises(rrt.RrtError) as e:
+            r.render(w, h, spp)
+        assert e.value.status == 1
+    bad = rrt.Scene()
+    with pytest.raises(rrt.RrtError):
+        r.upload(bad)  # no materials
+    assert r.intersect(helpers.make_rays([(0, 0, 5)], [(0, 0, -1)]))["prim_id"][0] == 0  # the old scene is still there
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.Renderer(device=99)
+    assert e.value.status == 1
+    with pytest.raises(rrt.RrtError):
+        rrt.Renderer(max_depth=0)
+    r.close()
