@@ -177,7 +177,13 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None, "kernel": "k_render", "kernel_ms": k_ms, "nodes_per_ray": nodes_per_ray,
                 "prims_per_ray": prims_per_ray, "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_step,
-                "samples_per_launch": samples}
+                "samples_per_launch": samples,
+                # fraction of the 64 lanes doing useful work in a node step / primitive test / shading pass
+                "lane_util_node": cs.node_visits / max(64 * cs.node_wave_steps, 1),
+                "lane_util_prim": cs.prim_tests / max(64 * cs.prim_wave_steps, 1),
+                "lane_util_shade": cs.rays / max(64 * cs.shade_wave_passes, 1),
+                "wave_steps_per_ray": {"node": 64 * cs.node_wave_steps / max(cs.rays, 1), "prim": 64 * cs.prim_wave_steps / max(cs.rays, 1),
+                                       "shade": 64 * cs.shade_wave_passes / max(cs.rays, 1)}}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene, width, height, spp, args.seed)
 

@@ -176,6 +176,12 @@ typedef struct rrt_stats {
     uint64_t samples;     /* iterations of the spp loop, reference src/main.rs:91                           */
     uint64_t node_visits; /* BVH nodes fetched   (only with RRT_CFG_COUNT_VISITS, else 0)                   */
     uint64_t prim_tests;  /* primitive tests run (only with RRT_CFG_COUNT_VISITS, else 0)                   */
+    /* Divergence of the render kernel (only with RRT_CFG_COUNT_VISITS): how often a 64-lane wavefront executed
+     * the node step / the primitive test / the shading pass.  node_visits / (64 * node_wave_steps) is the
+     * fraction of lanes doing useful work in a node step, and likewise for the other two.               */
+    uint64_t node_wave_steps;
+    uint64_t prim_wave_steps;
+    uint64_t shade_wave_passes;
     float kernel_ms;      /* HIP-event time of the render kernel on its stream                              */
     float reserved;
 } rrt_stats;

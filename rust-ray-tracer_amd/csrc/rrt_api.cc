@@ -284,11 +284,14 @@ rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32
         RRT_HIP(c, hipMalloc((void**)&c->d_partial, need));
         c->partial_bytes = need;
     }
+    // tuning overrides for experiments: RRT_CHUNKS (above), RRT_NODE_SHARE (0..64)
+    uint32_t node_share = DEFAULT_NODE_SHARE_64THS;
+    if (const char* e = std::getenv("RRT_NODE_SHARE")) node_share = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     RRT_HIP(c, hipMemsetAsync(c->d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
     RRT_HIP(c, launch_render(c->sdev, width, height, spp, spp_offset, d_accum, c->d_partial, n_chunks, c->d_counters,
                              reinterpret_cast<unsigned int*>(c->d_counters + 8), c->cu_count,
-                             (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, s));
+                             (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, node_share, s));
     RRT_HIP(c, hipEventRecord(c->ev_stop, s));
     c->last_stream = s;
     c->render_pending = true;
@@ -301,7 +304,7 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     if (!c->render_pending) return set_err(c, RRT_ERR_STATE, "rrt_render_stats: no render was issued");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     RRT_HIP(c, hipEventSynchronize(c->ev_stop));
-    unsigned long long h[3] = {0, 0, 0};
+    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
     RRT_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
     float ms = 0.f;
     RRT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
@@ -309,6 +312,9 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     stats->rays = h[0];
     stats->node_visits = h[1];
     stats->prim_tests = h[2];
+    stats->node_wave_steps = h[3];
+    stats->prim_wave_steps = h[4];
+    stats->shade_wave_passes = h[5];
     stats->samples = c->pending_samples;
     stats->kernel_ms = ms;
     return RRT_OK;

@@ -224,112 +224,170 @@ __device__ __forceinline__ void to_object_space(const InstRec& in, V3 o, V3 d, V
 
 // ---------------------------------------------------------------------------------------------
 // BVH traversal: closest hit = min (t, id) over the reference's per-primitive tests.
-// The slab test is conservative: each t carries the rounding of the subtraction and of the multiplication
-// (half an ulp each) plus the 1-ulp error of v_rcp_f32, i.e. at most 2 ulp on the near and on the far
-// side; widening the far side by 1e-6 relative (8 ulp) covers both (Ize, "Robust BVH Ray Traversal").
-// NaN slabs (0 * inf) drop out of min/max and count as hits, like f32::max/min in the reference's
-// src/bvh/aabb.rs:24-28.
+// The slab test only has to be conservative (exactness lives in the primitive tests).  A plane distance is
+// one fused multiply-add, t = plane * inv - origin * inv, with inv the hardware reciprocal (1 ulp) clamped to
+// +-1e30 so that axis-parallel rays give huge finite values instead of inf - inf.  Its error is a few ulp of
+// |origin * inv|, i.e. about 2^-22 * |origin| in space -- far inside the 2^-17 * scene-extent margin the
+// builder adds to every box -- plus a few ulp relative to t, covered by widening the far side by 1e-6
+// (Ize, "Robust BVH Ray Traversal").  NaN slabs drop out of min/max and count as hits, like f32::max/min
+// in the reference's src/bvh/aabb.rs:24-28.
 // `stack` points at this lane's slot of the LDS stack; entries are `stride` ints apart.
 // ---------------------------------------------------------------------------------------------
-// Reciprocal direction for the slab test only (never used by a primitive test): the hardware
-// approximation is enough because the comparison below carries its own error margin.
-__device__ __forceinline__ V3 slab_reciprocal(V3 d) {
-    return v3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+__device__ __forceinline__ float slab_rcp(float d) {
+    return fmaxf(fminf(__builtin_amdgcn_rcpf(d), 1e30f), -1e30f);
 }
+__device__ __forceinline__ V3 slab_reciprocal(V3 d) { return v3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z)); }
 
 struct TraceCounters {
-    uint32_t nodes, prims;
+    uint32_t nodes, prims;                      // per lane: node steps taken, primitive tests run
+    uint32_t wave_nodes, wave_prims, wave_shade; // per wavefront (kept by whichever lane is first active): passes executed
 };
 
+// True in exactly one of the currently active lanes.
+__device__ __forceinline__ bool first_active_lane() {
+    const unsigned long long m = __ballot(1);
+    return (unsigned)__lane_id() == (unsigned)__ffsll((long long)m) - 1u;
+}
+
+// Resumable traversal state of one lane.  The render kernel interleaves traversal with shading of the lanes
+// that have finished, so a ray's walk can be suspended between any two steps.
+struct Trav {
+    int cur;          // node / leaf reference being visited; REF_DONE when the walk is complete
+    int sp;           // stack entries in use
+    Best best;
+    V3 inv, noi;      // slab test constants of the ray in the current space: 1/direction and -origin/direction
+    V3 ro, rd;        // ray in the current space (instanced scenes only; otherwise the world ray is used)
+    uint32_t id_base; // id offset of the instance being traversed
+    int32_t cur_inst; // instance record being traversed, -1 at top level
+};
+
+__device__ __forceinline__ void trav_set_ray(Trav& T, V3 o, V3 d) {
+    T.inv = slab_reciprocal(d);
+    T.noi = v3(-(o.x * T.inv.x), -(o.y * T.inv.y), -(o.z * T.inv.z));
+}
+
+template <bool INST>
+__device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, int* stack, Trav& T) {
+    T.best.t = tmax; T.best.id = 0xFFFFFFFFu; T.best.u = 0.f; T.best.v = 0.f; T.best.what = 0u; T.best.inst = -1;
+    trav_set_ray(T, o, d);
+    if (INST) { T.ro = o; T.rd = d; }
+    T.id_base = 0;
+    T.cur_inst = -1;
+    stack[0] = REF_DONE;
+    T.sp = 1;
+    T.cur = S.root;
+}
+
+// Node pass: walks down while the current reference is an inner node (near child first, far child pushed).
+// Lanes that reach a leaf wait outside the loop; once fewer than `min_lanes` lanes are still descending the
+// pass ends for everybody, so that the waiting lanes get their primitive test instead of watching a handful
+// of lanes run node steps (min_lanes == 0: every lane descends until it is at a leaf).
+template <bool INST, bool COUNT>
+__device__ __forceinline__ void trav_nodes(const SceneDev& S, float tmin, int* stack, int stride, Trav& T,
+                                           TraceCounters& cnt, uint32_t min_lanes) {
+    const float far_scale = 1.000001f;
+    const V3 inv = T.inv, noi = T.noi;
+    int cur = T.cur, sp = T.sp;
+    while (cur >= 0) {
+        const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+        if (COUNT) {
+            cnt.nodes++;
+            if (first_active_lane()) cnt.wave_nodes++;
+        }
+        // left box
+        float t0x = __builtin_fmaf(a.x, inv.x, noi.x), t1x = __builtin_fmaf(a.w, inv.x, noi.x);
+        float t0y = __builtin_fmaf(a.y, inv.y, noi.y), t1y = __builtin_fmaf(b.x, inv.y, noi.y);
+        float t0z = __builtin_fmaf(a.z, inv.z, noi.z), t1z = __builtin_fmaf(b.y, inv.z, noi.z);
+        float ln = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+        float lf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
+        lf = fminf(lf, T.best.t);
+        // right box
+        t0x = __builtin_fmaf(b.z, inv.x, noi.x); t1x = __builtin_fmaf(c.y, inv.x, noi.x);
+        t0y = __builtin_fmaf(b.w, inv.y, noi.y); t1y = __builtin_fmaf(c.z, inv.y, noi.y);
+        t0z = __builtin_fmaf(c.x, inv.z, noi.z); t1z = __builtin_fmaf(c.w, inv.z, noi.z);
+        float rn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+        float rf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
+        rf = fminf(rf, T.best.t);
+        const bool hl = ln <= lf, hr = rn <= rf;
+        int left = __float_as_int(e.x), right = __float_as_int(e.y);
+        if (hl && hr) {
+            if (rn < ln) { int tmp = left; left = right; right = tmp; }
+            stack[sp * stride] = right;
+            sp++;
+            cur = left;
+        } else if (hl) {
+            cur = left;
+        } else if (hr) {
+            cur = right;
+        } else {
+            sp--;
+            cur = stack[sp * stride];
+        }
+        if ((uint32_t)__popcll(__ballot(cur >= 0)) < min_lanes) break;
+    }
+    T.cur = cur;
+    T.sp = sp;
+}
+
+// One leaf step (or stack marker): tests ONE primitive of the leaf with the reference's arithmetic; a triangle
+// leaf with more triangles stays current (reference advanced by one record), otherwise the next entry is popped.
+// One primitive per step keeps the cost of a pass the same for every lane, whatever its leaf holds.
+// Precondition: T.cur is negative and not REF_DONE.
+template <bool INST, bool COUNT>
+__device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float tmin, int* stack, int stride, Trav& T,
+                                          TraceCounters& cnt) {
+    const uint32_t ref = (uint32_t)T.cur;
+    const uint32_t kind = (ref >> 28) & 7u;
+    const uint32_t first = ref & REF_OFFSET_MASK;
+    const V3 ro = INST ? T.ro : o, rd = INST ? T.rd : d;
+    if (kind == KIND_TRI) {
+        test_triangle(S.tris, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+        if (COUNT) {
+            cnt.prims++;
+            if (first_active_lane()) cnt.wave_prims++;
+        }
+        if (((ref >> 25) & 7u) != 0u) {
+            T.cur = (int)(ref + 1u - (1u << 25));  // next record, one triangle fewer
+            return;
+        }
+    } else if (kind == KIND_SPHERE) {
+        test_sphere(S.spheres, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+        if (COUNT) cnt.prims++;
+    } else if (kind == KIND_RECT) {
+        test_rect(S.rects, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+        if (COUNT) cnt.prims++;
+    } else if (INST && kind == KIND_INST) {
+        const InstRec in = S.insts[first];
+        to_object_space(in, o, d, T.ro, T.rd);
+        trav_set_ray(T, T.ro, T.rd);
+        T.id_base = in.id_base;
+        T.cur_inst = (int32_t)first;
+        stack[T.sp * stride] = REF_INST_EXIT;
+        T.sp++;
+        T.cur = in.root;
+        return;
+    } else if (INST && kind == KIND_INST_EXIT) {
+        T.ro = o; T.rd = d;
+        trav_set_ray(T, o, d);
+        T.id_base = 0;
+        T.cur_inst = -1;
+    }
+    T.sp--;
+    T.cur = stack[T.sp * stride];
+}
+
+// Complete walk of one ray (used by the ray-batch kernel): the same passes as the render kernel, run to the end.
 template <bool INST, bool COUNT>
 __device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin, float tmax, int* stack, int stride,
                                       Best& best, TraceCounters& cnt) {
-    best.t = tmax; best.id = 0xFFFFFFFFu; best.u = 0.f; best.v = 0.f; best.what = 0u; best.inst = -1;
-    const float far_scale = 1.000001f;
-
-    V3 ro = o, rd = d;  // ray in the space being traversed (world, or an instance's object space)
-    V3 inv = slab_reciprocal(rd);
-    uint32_t id_base = 0;
-    int32_t cur_inst = -1;
-
-    int sp = 0;
-    stack[0] = REF_DONE;
-    sp = 1;
-    int cur = S.root;
-
-    for (;;) {
-        // ---- inner nodes
-        while (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            const float4 a = np[0], b = np[1], c = np[2], e = np[3];
-            if (COUNT) cnt.nodes++;
-            // left box
-            float t0x = (a.x - ro.x) * inv.x, t1x = (a.w - ro.x) * inv.x;
-            float t0y = (a.y - ro.y) * inv.y, t1y = (b.x - ro.y) * inv.y;
-            float t0z = (a.z - ro.z) * inv.z, t1z = (b.y - ro.z) * inv.z;
-            float ln = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-            float lf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
-            lf = fminf(lf, best.t);
-            // right box
-            t0x = (b.z - ro.x) * inv.x; t1x = (c.y - ro.x) * inv.x;
-            t0y = (b.w - ro.y) * inv.y; t1y = (c.z - ro.y) * inv.y;
-            t0z = (c.x - ro.z) * inv.z; t1z = (c.w - ro.z) * inv.z;
-            float rn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-            float rf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
-            rf = fminf(rf, best.t);
-            const bool hl = ln <= lf, hr = rn <= rf;
-            int left = __float_as_int(e.x), right = __float_as_int(e.y);
-            if (hl && hr) {
-                if (rn < ln) { int tmp = left; left = right; right = tmp; }
-                stack[sp * stride] = right;
-                sp++;
-                cur = left;
-            } else if (hl) {
-                cur = left;
-            } else if (hr) {
-                cur = right;
-            } else {
-                sp--;
-                cur = stack[sp * stride];
-            }
-        }
-        if (cur == REF_DONE) break;
-
-        // ---- leaf (or marker)
-        const uint32_t ref = (uint32_t)cur;
-        const uint32_t kind = (ref >> 28) & 7u;
-        const uint32_t first = ref & REF_OFFSET_MASK;
-        if (kind == KIND_TRI) {
-            const uint32_t count = ((ref >> 25) & 7u) + 1u;
-            for (uint32_t k = 0; k < count; ++k) {
-                test_triangle(S.tris, first + k, ro, rd, tmin, id_base, cur_inst, best);
-            }
-            if (COUNT) cnt.prims += count;
-        } else if (kind == KIND_SPHERE) {
-            test_sphere(S.spheres, first, ro, rd, tmin, id_base, cur_inst, best);
-            if (COUNT) cnt.prims++;
-        } else if (kind == KIND_RECT) {
-            test_rect(S.rects, first, ro, rd, tmin, id_base, cur_inst, best);
-            if (COUNT) cnt.prims++;
-        } else if (INST && kind == KIND_INST) {
-            const InstRec in = S.insts[first];
-            to_object_space(in, o, d, ro, rd);
-            inv = slab_reciprocal(rd);
-            id_base = in.id_base;
-            cur_inst = (int32_t)first;
-            stack[sp * stride] = REF_INST_EXIT;
-            sp++;
-            cur = in.root;
-            continue;
-        } else if (INST && kind == KIND_INST_EXIT) {
-            ro = o; rd = d;
-            inv = slab_reciprocal(rd);
-            id_base = 0;
-            cur_inst = -1;
-        }
-        sp--;
-        cur = stack[sp * stride];
+    Trav T;
+    trav_begin<INST>(S, o, d, tmax, stack, T);
+    while (T.cur != REF_DONE) {
+        trav_nodes<INST, COUNT>(S, tmin, stack, stride, T, cnt, 0u);  // 0: descend until this lane is at a leaf
+        if (T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stack, stride, T, cnt);
     }
+    best = T.best;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -12,13 +12,19 @@ namespace rrt {
 // Number of sample chunks a frame of `spp` samples per pixel is cut into (work item = tile x chunk).
 uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp);
 
-// d_counters: 3 x u64 in device memory {rays, node visits, primitive tests}; the kernel ADDS to them.
-// d_heads:    N_QUEUES (8) x u32 work-queue heads, zero before the launch.
+// Share (in 64ths) of the walking lanes that must be descending for a node pass to run; 40/64 measured best
+// on MI355X for both the 968-triangle and the 1M-triangle scene.
+static constexpr uint32_t DEFAULT_NODE_SHARE_64THS = 40u;
+
+// d_counters: 6 x u64 in device memory {rays, node visits, primitive tests, wave-level node passes, primitive
+//             passes, shading passes}; the kernel ADDS to them.
+// d_heads:    8 x u32 work-queue heads, zero before the launch.
 // n_chunks > 1: the kernel writes n_chunks partial images (each width*height*3 floats) to d_partial and a second
 // kernel sums them into d_accum in chunk order; n_chunks == 1: the kernel writes d_accum directly.
 hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
                          float* d_accum, float* d_partial, uint32_t n_chunks, unsigned long long* d_counters,
-                         unsigned int* d_heads, int cu_count, bool count_visits, hipStream_t stream);
+                         unsigned int* d_heads, int cu_count, bool count_visits, uint32_t node_share_64ths,
+                         hipStream_t stream);
 hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, float tmin, float tmax, rrt_hit* d_out,
                             hipStream_t stream);
 hipError_t launch_tonemap(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb8,

@@ -120,6 +120,7 @@ struct RenderGeom {
     uint32_t width, height, spp, spp_offset;
     uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;
     uint32_t n_work;
+    uint32_t node_share_64ths;  // a node pass runs while at least this share (in 64ths) of the walking lanes descends
 };
 
 // Per-lane traversal stack entries (LDS).  One inner-node step pushes at most one entry, so the stack never
