@@ -85,6 +85,20 @@ def cpu_baseline(scene, width, height, spp_full, seed, budget_s=15.0):
             "samples_per_s": width * height * spp / dt}
 
 
+def measured_traffic(config: int, width: int, height: int, spp: int):
+    """HBM bytes per k_render launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json, written from
+    tools/prof.sh output); None when this exact workload has not been profiled."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            row = json.load(f).get(str(config))
+    except (OSError, ValueError):
+        return None
+    if not row or (row["width"], row["height"], row["spp_per_gpu"]) != (width, height, spp):
+        return None
+    return float(row["bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +189,7 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "kernel": "k_render", "kernel_ms": k_ms, "nodes_per_ray": nodes_per_ray,
+                "traffic": measured_traffic(args.config, width, height, spp), "kernel": "k_render", "kernel_ms": k_ms, "nodes_per_ray": nodes_per_ray,
                 "prims_per_ray": prims_per_ray, "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_step,
                 "samples_per_launch": samples,
                 # fraction of the 64 lanes doing useful work in a node step / primitive test / shading pass

@@ -15,6 +15,9 @@ pass pmc1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
 pass pmc2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
 pass pmc3 TCC_HIT_sum TCC_MISS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
 pass pmc4 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
-pass pmc5 SQ_INSTS_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_LEVEL_WAVES SQ_ACCUM_PREV_HIRES SQ_INSTS_FLAT
+pass pmc5 SQ_INSTS_VALU SQ_WAIT_INST_VMEM SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_INSTS_FLAT
+# HBM-side traffic: FETCH_SIZE takes 3 TCC slots and WRITE_SIZE 2, so one pass each (values in KB)
+pass pmc6 FETCH_SIZE
+pass pmc7 WRITE_SIZE
 python3 tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
