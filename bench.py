@@ -27,7 +27,7 @@ import torch.distributed as dist  # noqa: E402
 import rrt_pkg  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-NODE_BYTES, PRIM_BYTES, ACCUM_BYTES_PER_SAMPLE_AT_SPP1 = 64, 48, 12
+NODE_BYTES, PRIM_BYTES, ACCUM_BYTES_PER_SAMPLE_AT_SPP1 = 32, 48, 12
 
 
 def build_scene(rrt, config: int):

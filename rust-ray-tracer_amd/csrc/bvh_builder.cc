@@ -191,7 +191,6 @@ struct Builder {
         }
         nd.left = l.ref;
         nd.right = r.ref;
-        nd.pad0 = nd.pad1 = 0;
         Child out;
         out.ref = (int32_t)node;
         out.box = box;

@@ -157,7 +157,7 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     RRT_HIP(c, hipDeviceSynchronize());
     free_scene(c);
     uint64_t total = 0;
-    if ((st = upload(c, hs.nodes, &c->d_nodes, total)) != RRT_OK || (st = upload(c, hs.tris, &c->d_tris, total)) != RRT_OK ||
+    if ((st = upload(c, hs.qnodes, &c->d_nodes, total)) != RRT_OK || (st = upload(c, hs.tris, &c->d_tris, total)) != RRT_OK ||
         (st = upload(c, hs.spheres, &c->d_spheres, total)) != RRT_OK || (st = upload(c, hs.rects, &c->d_rects, total)) != RRT_OK ||
         (st = upload(c, hs.insts, &c->d_insts, total)) != RRT_OK || (st = upload(c, hs.mats, &c->d_mats, total)) != RRT_OK ||
         (st = upload(c, hs.lights, &c->d_lights, total)) != RRT_OK) {
@@ -167,7 +167,7 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     const auto t2 = std::chrono::steady_clock::now();
 
     SceneDev& S = c->sdev;
-    S.nodes = (const BvhNode*)c->d_nodes; S.tris = (const TriRec*)c->d_tris; S.spheres = (const SphereRec*)c->d_spheres;
+    S.nodes = (const QNode*)c->d_nodes; S.tris = (const TriRec*)c->d_tris; S.spheres = (const SphereRec*)c->d_spheres;
     S.rects = (const RectRec*)c->d_rects; S.insts = (const InstRec*)c->d_insts; S.mats = (const MatRec*)c->d_mats;
     S.lights = (const LightRec*)c->d_lights;
     S.light_count = (uint32_t)hs.lights.size();
@@ -179,6 +179,7 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     S.t_min = c->cfg.t_min;
     S.max_depth = c->cfg.max_depth;
     S.seed = c->cfg.seed;
+    S.grid = hs.grid;
 
     c->info.prim_count = hs.prim_count;
     c->info.node_count = (uint32_t)hs.nodes.size();
@@ -211,7 +212,7 @@ rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
     out->tri_count = (uint32_t)hs.tris.size();
     out->bvh_depth = hs.depth;
     auto sz = [](size_t n, size_t rec) { return (uint64_t)(n ? n : 1) * rec; };
-    out->device_bytes = sz(hs.nodes.size(), sizeof(BvhNode)) + sz(hs.tris.size(), sizeof(TriRec)) + sz(hs.spheres.size(), sizeof(SphereRec)) +
+    out->device_bytes = sz(hs.qnodes.size(), sizeof(QNode)) + sz(hs.tris.size(), sizeof(TriRec)) + sz(hs.spheres.size(), sizeof(SphereRec)) +
                         sz(hs.rects.size(), sizeof(RectRec)) + sz(hs.insts.size(), sizeof(InstRec)) + sz(hs.mats.size(), sizeof(MatRec)) +
                         sz(hs.lights.size(), sizeof(LightRec));
     out->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

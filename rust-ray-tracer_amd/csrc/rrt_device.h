@@ -224,13 +224,15 @@ __device__ __forceinline__ void to_object_space(const InstRec& in, V3 o, V3 d, V
 
 // ---------------------------------------------------------------------------------------------
 // BVH traversal: closest hit = min (t, id) over the reference's per-primitive tests.
-// The slab test only has to be conservative (exactness lives in the primitive tests).  A plane distance is
-// one fused multiply-add, t = plane * inv - origin * inv, with inv the hardware reciprocal (1 ulp) clamped to
-// +-1e30 so that axis-parallel rays give huge finite values instead of inf - inf.  Its error is a few ulp of
-// |origin * inv|, i.e. about 2^-22 * |origin| in space -- far inside the 2^-17 * scene-extent margin the
-// builder adds to every box -- plus a few ulp relative to t, covered by widening the far side by 1e-6
-// (Ize, "Robust BVH Ray Traversal").  NaN slabs drop out of min/max and count as hits, like f32::max/min
-// in the reference's src/bvh/aabb.rs:24-28.
+// The slab test only has to be conservative (exactness lives in the primitive tests).  Child boxes are stored
+// as plane indices q on the grid of their BVH, plane(q) = origin + q * step, and a plane's ray distance is one
+// fused multiply-add, t = q * A + B, with A = step * inv, B = (origin - ray origin) * inv and inv the hardware
+// reciprocal of the direction (1 ulp) clamped to +-1e30, so that axis-parallel rays give huge finite values
+// instead of inf - inf.  The error of t is a few ulp of the distances involved, i.e. about 2^-22 * (scene
+// extent) in space -- far inside the 2^-17 * scene-extent margin the builder adds to every box before it
+// rounds the box outwards to the grid -- plus a few ulp relative to t, covered by widening the far side by
+// 1e-6 (Ize, "Robust BVH Ray Traversal").  The reference's own box test, src/bvh/aabb.rs:14-36, is looser
+// still: it accepts every box the ray's three slab intervals each reach.
 // `stack` points at this lane's slot of the LDS stack; entries are `stride` ints apart.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float slab_rcp(float d) {
@@ -255,21 +257,22 @@ struct Trav {
     int cur;          // node / leaf reference being visited; REF_DONE when the walk is complete
     int sp;           // stack entries in use
     Best best;
-    V3 inv, noi;      // slab test constants of the ray in the current space: 1/direction and -origin/direction
+    V3 ga, gb;        // slab test constants of the ray on the current BVH's grid: plane q lies at t = q * ga + gb
     V3 ro, rd;        // ray in the current space (instanced scenes only; otherwise the world ray is used)
     uint32_t id_base; // id offset of the instance being traversed
     int32_t cur_inst; // instance record being traversed, -1 at top level
 };
 
-__device__ __forceinline__ void trav_set_ray(Trav& T, V3 o, V3 d) {
-    T.inv = slab_reciprocal(d);
-    T.noi = v3(-(o.x * T.inv.x), -(o.y * T.inv.y), -(o.z * T.inv.z));
+__device__ __forceinline__ void trav_set_ray(Trav& T, V3 o, V3 d, const float* grid_origin, const float* grid_step) {
+    const V3 inv = slab_reciprocal(d);
+    T.ga = v3(grid_step[0] * inv.x, grid_step[1] * inv.y, grid_step[2] * inv.z);
+    T.gb = v3((grid_origin[0] - o.x) * inv.x, (grid_origin[1] - o.y) * inv.y, (grid_origin[2] - o.z) * inv.z);
 }
 
 template <bool INST>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, int* stack, Trav& T) {
     T.best.t = tmax; T.best.id = 0xFFFFFFFFu; T.best.u = 0.f; T.best.v = 0.f; T.best.what = 0u; T.best.inst = -1;
-    trav_set_ray(T, o, d);
+    trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
     if (INST) { T.ro = o; T.rd = d; }
     T.id_base = 0;
     T.cur_inst = -1;
@@ -286,31 +289,31 @@ template <bool INST, bool COUNT>
 __device__ __forceinline__ void trav_nodes(const SceneDev& S, float tmin, int* stack, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes) {
     const float far_scale = 1.000001f;
-    const V3 inv = T.inv, noi = T.noi;
+    const V3 ga = T.ga, gb = T.gb;
     int cur = T.cur, sp = T.sp;
     while (cur >= 0) {
-        const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-        const float4 a = np[0], b = np[1], c = np[2], e = np[3];
+        const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
+        const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
         if (COUNT) {
             cnt.nodes++;
             if (first_active_lane()) cnt.wave_nodes++;
         }
         // left box
-        float t0x = __builtin_fmaf(a.x, inv.x, noi.x), t1x = __builtin_fmaf(a.w, inv.x, noi.x);
-        float t0y = __builtin_fmaf(a.y, inv.y, noi.y), t1y = __builtin_fmaf(b.x, inv.y, noi.y);
-        float t0z = __builtin_fmaf(a.z, inv.z, noi.z), t1z = __builtin_fmaf(b.y, inv.z, noi.z);
+        float t0x = __builtin_fmaf((float)(a.z & 0xFFFFu), ga.x, gb.x), t1x = __builtin_fmaf((float)(a.z >> 16), ga.x, gb.x);
+        float t0y = __builtin_fmaf((float)(a.w & 0xFFFFu), ga.y, gb.y), t1y = __builtin_fmaf((float)(a.w >> 16), ga.y, gb.y);
+        float t0z = __builtin_fmaf((float)(b.x & 0xFFFFu), ga.z, gb.z), t1z = __builtin_fmaf((float)(b.x >> 16), ga.z, gb.z);
         float ln = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
         float lf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
         lf = fminf(lf, T.best.t);
         // right box
-        t0x = __builtin_fmaf(b.z, inv.x, noi.x); t1x = __builtin_fmaf(c.y, inv.x, noi.x);
-        t0y = __builtin_fmaf(b.w, inv.y, noi.y); t1y = __builtin_fmaf(c.z, inv.y, noi.y);
-        t0z = __builtin_fmaf(c.x, inv.z, noi.z); t1z = __builtin_fmaf(c.w, inv.z, noi.z);
+        t0x = __builtin_fmaf((float)(b.y & 0xFFFFu), ga.x, gb.x); t1x = __builtin_fmaf((float)(b.y >> 16), ga.x, gb.x);
+        t0y = __builtin_fmaf((float)(b.z & 0xFFFFu), ga.y, gb.y); t1y = __builtin_fmaf((float)(b.z >> 16), ga.y, gb.y);
+        t0z = __builtin_fmaf((float)(b.w & 0xFFFFu), ga.z, gb.z); t1z = __builtin_fmaf((float)(b.w >> 16), ga.z, gb.z);
         float rn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
         float rf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
         rf = fminf(rf, T.best.t);
         const bool hl = ln <= lf, hr = rn <= rf;
-        int left = __float_as_int(e.x), right = __float_as_int(e.y);
+        int left = (int)a.x, right = (int)a.y;
         if (hl && hr) {
             if (rn < ln) { int tmp = left; left = right; right = tmp; }
             stack[sp * stride] = right;
@@ -360,7 +363,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
     } else if (INST && kind == KIND_INST) {
         const InstRec in = S.insts[first];
         to_object_space(in, o, d, T.ro, T.rd);
-        trav_set_ray(T, T.ro, T.rd);
+        trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
         T.id_base = in.id_base;
         T.cur_inst = (int32_t)first;
         stack[T.sp * stride] = REF_INST_EXIT;
@@ -369,7 +372,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         return;
     } else if (INST && kind == KIND_INST_EXIT) {
         T.ro = o; T.rd = d;
-        trav_set_ray(T, o, d);
+        trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
         T.id_base = 0;
         T.cur_inst = -1;
     }

@@ -9,6 +9,7 @@
 // once per item (12 bytes per pixel).  Traversal stacks live in LDS (STACK_DEPTH dwords per lane, laid
 // out [entry][thread] so that a wave access touches 64 consecutive banks).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "rrt_device.h"
 #include "rrt_kernels.h"
@@ -267,6 +268,11 @@ static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, 
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<INST, COUNT>, RENDER_BLOCK, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = n > 0 ? n : 1;
+        // experiment knob: fewer resident workgroups per CU (occupancy sensitivity)
+        if (const char* env = getenv("RRT_BLOCKS_PER_CU")) {
+            const int v = atoi(env);
+            if (v > 0 && v < blocks_per_cu) blocks_per_cu = v;
+        }
     }
     unsigned long long blocks = (unsigned long long)blocks_per_cu * (unsigned)cu_count;
     const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;

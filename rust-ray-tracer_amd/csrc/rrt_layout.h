@@ -2,12 +2,12 @@
 //
 // Everything a ray touches during traversal is a 16-byte-aligned record read with
 // global_load_dwordx4:
-//   BvhNode   64 B  both child boxes + both child references (the idea of the reference's
+//   QNode     32 B  both child references + both child boxes on a 16-bit grid (the idea of the reference's
 //                   unfinished flat BVH, src/bvh/mod.rs:19-25: a node stores its children's boxes)
 //   TriRec    48 B  v0 | id, v0v1 | material, v0v2 | -      (reference src/geometry/triangle.rs:13-20)
 //   SphereRec 32 B  centre, radius | id, material           (reference src/geometry/sphere.rs:17-22)
 //   RectRec   32 B  a0,a1,b0,b1 | k, axis+flags, id, material (reference src/geometry/aarect.rs:14-21)
-//   InstRec   48 B  Translate(RotateY(mesh))                (reference src/geometry/transform.rs:9-12,44-49)
+//   InstRec   64 B  Translate(RotateY(mesh)) + the mesh BVH's grid (reference src/geometry/transform.rs:9-12,44-49)
 //   MatRec    32 B  kind, rgb, param                        (reference src/material/mod.rs:47-194)
 #ifndef RRT_LAYOUT_H
 #define RRT_LAYOUT_H
@@ -33,17 +33,30 @@ static inline uint32_t make_leaf_ref(uint32_t kind, uint32_t first, uint32_t cou
     return REF_LEAF | (kind << 28) | (((count - 1u) & 7u) << 25) | (first & REF_OFFSET_MASK);
 }
 
-struct alignas(16) BvhNode {
-    // a = (L.min.x, L.min.y, L.min.z, L.max.x)  b = (L.max.y, L.max.z, R.min.x, R.min.y)
-    // c = (R.min.z, R.max.x, R.max.y, R.max.z)  d = (left ref, right ref, 0, 0)
+// Host-side node as the builder produces it (full-precision child boxes); never uploaded.
+struct BvhNode {
     float lmin[3];
     float lmax[3];
     float rmin[3];
     float rmax[3];
     int32_t left, right;
-    uint32_t pad0, pad1;
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// Every BVH (the top level and each mesh) carries a grid of 65536 planes per axis, plane(q) = origin + q * step,
+// that covers its root box.  A child box is stored as plane indices rounded outwards, so the stored box contains
+// the builder's box, and a node shrinks to two 16-byte loads.  The traversal never forms plane(q) itself: with
+// A = step / dir and B = (origin - ray origin) / dir per axis, the plane's ray distance is fma(q, A, B).
+struct Grid {
+    float origin[3];
+    float step[3];
+};
+
+struct alignas(16) QNode {
+    int32_t left, right;      // child references
+    uint32_t lbox[3];         // left child, per axis: bits 15..0 = min plane index, bits 31..16 = max plane index
+    uint32_t rbox[3];         // right child
+};
+static_assert(sizeof(QNode) == 32, "QNode must be 32 bytes");
 
 struct alignas(16) TriRec {
     float v0[3];   uint32_t id;
@@ -69,9 +82,10 @@ struct alignas(16) InstRec {
     float offset[3];   uint32_t id_base;   // ids of the instance's primitives = id_base + local id
     float sin_t, cos_t; int32_t root;      // root node of the mesh's BVH
     uint32_t pad0;
-    uint32_t pad1[4];
+    float grid_origin[3]; uint32_t pad1;   // grid of the mesh's BVH (object space)
+    float grid_step[3];   uint32_t pad2;
 };
-static_assert(sizeof(InstRec) == 48, "InstRec must be 48 bytes");
+static_assert(sizeof(InstRec) == 64, "InstRec must be 64 bytes");
 
 struct alignas(16) MatRec {
     uint32_t kind;  float r, g, b;
@@ -95,7 +109,7 @@ struct CameraRec {
 };
 
 struct SceneDev {
-    const BvhNode* nodes;
+    const QNode* nodes;
     const TriRec* tris;
     const SphereRec* spheres;
     const RectRec* rects;
@@ -111,6 +125,7 @@ struct SceneDev {
     float t_min;
     uint32_t max_depth;
     uint32_t seed;
+    Grid grid;          // grid of the top-level BVH (world space)
 };
 
 // Launch geometry of the render kernel.  The frame is cut into 8x8 pixel tiles and the sample range into

@@ -63,6 +63,7 @@ struct Expander {
         uint32_t prim_count;
         uint32_t depth;
         float mn[3], mx[3];
+        Grid grid;
     };
     bool expand(const rrt_object* objs, uint32_t n_objs, uint32_t& id, std::vector<BuildPrim>& prims,
                 const std::vector<MeshInfo>* meshes) {
@@ -155,6 +156,7 @@ struct Expander {
                     rec.sin_t = in.sin_theta;
                     rec.cos_t = in.cos_theta;
                     rec.root = mi.root;
+                    for (int a = 0; a < 3; ++a) { rec.grid_origin[a] = mi.grid.origin[a]; rec.grid_step[a] = mi.grid.step[a]; }
                     rec.id_base = id;
                     id += mi.prim_count;
                     BuildPrim p;
@@ -191,6 +193,56 @@ static float max_abs3(const float* v) {
         m = std::max(m, std::fabs(v[i]));
     }
     return m;
+}
+
+// Grid of 65536 planes per axis over a BVH's root box [mn, mx], with two steps of slack at the low end.  The step
+// is at least 2^-20 of the largest coordinate, so that rounding the origin to a float moves it by a small
+// fraction of a step.
+static Grid make_grid(const float* mn, const float* mx) {
+    Grid g;
+    for (int a = 0; a < 3; ++a) {
+        double lo = mn[a], hi = mx[a];
+        if (!(hi >= lo)) { lo = 0.0; hi = 0.0; }  // empty BVH
+        const double mag = std::max(std::fabs(lo), std::fabs(hi));
+        double step = std::max((hi - lo) / 65528.0, mag * (1.0 / 1048576.0));
+        step = std::max(step, 1e-30);
+        float stepf = (float)step;
+        float originf = (float)(lo - 2.0 * (double)stepf);
+        while ((double)originf > lo) originf = std::nextafterf(originf, -INFINITY);
+        while ((double)originf + 65535.0 * (double)stepf < hi) stepf = std::nextafterf(stepf, INFINITY);
+        g.origin[a] = originf;
+        g.step[a] = stepf;
+    }
+    return g;
+}
+
+// Plane indices of one child box, rounded outwards by one extra plane: the stored box contains [mn, mx].
+static void quantize_box(const Grid& g, const float* mn, const float* mx, uint32_t* out) {
+    for (int a = 0; a < 3; ++a) {
+        const double o = g.origin[a], s = g.step[a];
+        double qlo = std::floor(((double)mn[a] - o) / s) - 1.0;
+        double qhi = std::ceil(((double)mx[a] - o) / s) + 1.0;
+        if (!(qlo >= 0.0)) qlo = 0.0;          // also catches the NaN of an empty slot's sentinel box
+        if (!(qhi <= 65535.0)) qhi = 65535.0;
+        if (qlo > 65535.0) qlo = 65535.0;
+        if (qhi < 0.0) qhi = 0.0;
+        out[a] = (uint32_t)qlo | ((uint32_t)qhi << 16);
+    }
+}
+
+// Appends the quantized form of hs.nodes[first..] (one BVH, root box [mn, mx]) to hs.qnodes.
+static Grid quantize_nodes(HostScene& hs, size_t first, const float* mn, const float* mx) {
+    const Grid g = make_grid(mn, mx);
+    hs.qnodes.resize(hs.nodes.size());
+    for (size_t i = first; i < hs.nodes.size(); ++i) {
+        const BvhNode& n = hs.nodes[i];
+        QNode& q = hs.qnodes[i];
+        q.left = n.left;
+        q.right = n.right;
+        quantize_box(g, n.lmin, n.lmax, q.lbox);
+        quantize_box(g, n.rmin, n.rmax, q.rbox);
+    }
+    return g;
 }
 
 }  // namespace
@@ -272,7 +324,9 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         uint32_t id = 0;
         if (!ex.expand(d->mesh_objects + m.first_object, m.object_count, id, prims, nullptr)) return RRT_ERR_INVALID;
         const uint32_t budget = MAX_TREE_DEPTH - top_budget - 1u;
+        const size_t first_node = hs.nodes.size();
         BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), budget, threads);
+        meshes[mi].grid = quantize_nodes(hs, first_node, br.root_min, br.root_max);
         if (br.depth > budget) { err = "mesh too large for the traversal stack of an instanced scene"; return RRT_ERR_INVALID; }
         meshes[mi].root = br.root;
         meshes[mi].prim_count = id;
@@ -285,7 +339,9 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     std::vector<BuildPrim> prims;
     uint32_t id = 0;
     if (!ex.expand(d->world, d->world_count, id, prims, &meshes)) return RRT_ERR_INVALID;
+    const size_t first_node = hs.nodes.size();
     BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), top_budget, threads);
+    hs.grid = quantize_nodes(hs, first_node, br.root_min, br.root_max);
     if (br.depth + (hs.insts.empty() ? 0u : deepest_mesh + 1u) > MAX_TREE_DEPTH) {
         err = "scene too deep for the traversal stack";
         return RRT_ERR_INVALID;

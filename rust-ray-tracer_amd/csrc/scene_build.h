@@ -11,7 +11,9 @@
 namespace rrt {
 
 struct HostScene {
-    std::vector<BvhNode> nodes;
+    std::vector<BvhNode> nodes;   // builder output (full-precision boxes), host only
+    std::vector<QNode> qnodes;    // the same nodes on their BVH's 16-bit grid: what is uploaded
+    Grid grid{};                  // grid of the top-level BVH
     std::vector<TriRec> tris;
     std::vector<SphereRec> spheres;
     std::vector<RectRec> rects;

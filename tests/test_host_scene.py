@@ -81,8 +81,8 @@ def test_large_mesh_build_is_bounded_and_fast(rrt):
     assert info.prim_count == 2 * 256 * 256 and info.tri_count == info.prim_count
     assert info.bvh_depth <= 29
     assert info.node_count < info.prim_count  # several triangles per leaf
-    # 64-byte nodes + 48-byte triangle records + one record each of the (empty) other arrays and the material
-    assert info.device_bytes == info.node_count * 64 + info.tri_count * 48 + 32 + 32 + 48 + 32 + 32
+    # 32-byte nodes + 48-byte triangle records + one record each of the (empty) other arrays and the material
+    assert info.device_bytes == info.node_count * 32 + info.tri_count * 48 + 32 + 32 + 64 + 32 + 32
 
 
 def test_image_width_follows_the_reference_cast(rrt):
