@@ -182,6 +182,7 @@ typedef struct rrt_stats {
     uint64_t node_wave_steps;
     uint64_t prim_wave_steps;
     uint64_t shade_wave_passes;
+    uint64_t refill_wave_passes; /* ray batches only: passes in which a wavefront's idle lanes drew new rays  */
     float kernel_ms;      /* HIP-event time of the render kernel on its stream                              */
     float reserved;
 } rrt_stats;
@@ -227,7 +228,8 @@ rrt_status rrt_render(rrt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
                       float* accum, rrt_stats* stats);
 rrt_status rrt_render_device(rrt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
                              float* d_accum, void* stream);
-/* Blocks until the stream of the last rrt_render_device call has drained, then reports its counters. */
+/* Blocks until the stream of the last rrt_render_device or rrt_intersect_device call has drained, then reports
+ * its counters (for a ray batch: rays = n, samples = 0). */
 rrt_status rrt_render_stats(rrt_ctx* ctx, rrt_stats* stats);
 
 /* ---- tone map ----  replaces: `get_color(color, samples)` + the flipped `put_pixel`

@@ -41,6 +41,7 @@ struct rrt_ctx {
     hipStream_t last_stream = nullptr;
     bool render_pending = false;
     uint64_t pending_samples = 0;
+    uint64_t pending_rays = 0;  // ray count of a pending ray batch (its kernel does not count rays itself)
 };
 
 namespace {
@@ -234,7 +235,21 @@ rrt_status rrt_intersect_device(rrt_ctx* c, const rrt_ray* d_rays, size_t n, flo
     if (!d_rays || !d_out) return set_err(c, RRT_ERR_INVALID, "rrt_intersect_device: NULL buffer");
     if (n > 0x7FFFFFFFull * 64ull) return set_err(c, RRT_ERR_INVALID, "rrt_intersect_device: batch too large");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
-    RRT_HIP(c, launch_intersect(c->sdev, d_rays, n, t_min, t_max, d_out, (hipStream_t)stream));
+    if (n > 0xF0000000ull) return set_err(c, RRT_ERR_INVALID, "rrt_intersect_device: batch too large");
+    hipStream_t s = (hipStream_t)stream;
+    RenderTuning tuning;
+    if (const char* e = std::getenv("RRT_NODE_SHARE")) tuning.node_share_64ths = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RRT_REFILL_MIN")) tuning.refill_min = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+    RRT_HIP(c, hipMemsetAsync(c->d_counters, 0, 256, s));
+    RRT_HIP(c, hipEventRecord(c->ev_start, s));
+    RRT_HIP(c, launch_intersect(c->sdev, d_rays, n, t_min, t_max, d_out, c->d_counters,
+                                reinterpret_cast<unsigned int*>(c->d_counters + 8), c->cu_count,
+                                (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, tuning, s));
+    RRT_HIP(c, hipEventRecord(c->ev_stop, s));
+    c->last_stream = s;
+    c->render_pending = true;
+    c->pending_samples = 0;
+    c->pending_rays = n;
     return RRT_OK;
 }
 
@@ -286,17 +301,18 @@ rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32
         c->partial_bytes = need;
     }
     // tuning overrides for experiments: RRT_CHUNKS (above), RRT_NODE_SHARE (0..64)
-    uint32_t node_share = DEFAULT_NODE_SHARE_64THS;
-    if (const char* e = std::getenv("RRT_NODE_SHARE")) node_share = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
+    RenderTuning tuning;
+    if (const char* e = std::getenv("RRT_NODE_SHARE")) tuning.node_share_64ths = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     RRT_HIP(c, hipMemsetAsync(c->d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
     RRT_HIP(c, launch_render(c->sdev, width, height, spp, spp_offset, d_accum, c->d_partial, n_chunks, c->d_counters,
                              reinterpret_cast<unsigned int*>(c->d_counters + 8), c->cu_count,
-                             (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, node_share, s));
+                             (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, tuning, s));
     RRT_HIP(c, hipEventRecord(c->ev_stop, s));
     c->last_stream = s;
     c->render_pending = true;
     c->pending_samples = (uint64_t)width * height * spp;
+    c->pending_rays = 0;
     return RRT_OK;
 }
 
@@ -305,17 +321,18 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     if (!c->render_pending) return set_err(c, RRT_ERR_STATE, "rrt_render_stats: no render was issued");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     RRT_HIP(c, hipEventSynchronize(c->ev_stop));
-    unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
     RRT_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
     float ms = 0.f;
     RRT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     std::memset(stats, 0, sizeof *stats);
-    stats->rays = h[0];
+    stats->rays = c->pending_rays ? c->pending_rays : h[0];
     stats->node_visits = h[1];
     stats->prim_tests = h[2];
     stats->node_wave_steps = h[3];
     stats->prim_wave_steps = h[4];
     stats->shade_wave_passes = h[5];
+    stats->refill_wave_passes = h[6];
     stats->samples = c->pending_samples;
     stats->kernel_ms = ms;
     return RRT_OK;

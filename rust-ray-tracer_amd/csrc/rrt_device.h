@@ -230,9 +230,13 @@ __device__ __forceinline__ void to_object_space(const InstRec& in, V3 o, V3 d, V
 // reciprocal of the direction (1 ulp) clamped to +-1e30, so that axis-parallel rays give huge finite values
 // instead of inf - inf.  The error of t is a few ulp of the distances involved, i.e. about 2^-22 * (scene
 // extent) in space -- far inside the 2^-17 * scene-extent margin the builder adds to every box before it
-// rounds the box outwards to the grid -- plus a few ulp relative to t, covered by widening the far side by
-// 1e-6 (Ize, "Robust BVH Ray Traversal").  The reference's own box test, src/bvh/aabb.rs:14-36, is looser
-// still: it accepts every box the ray's three slab intervals each reach.
+// rounds the box outwards to the grid; a plane's error relative to its t is a displacement of the plane by
+// that fraction of its distance from the ray origin, which the same margin covers for every ray that starts
+// within 32 scene extents.  The reference's own box test, src/bvh/aabb.rs:14-36, is looser still: it accepts
+// every box the ray's three slab intervals each reach.
+// A node stores, per axis, the min plane index in the low and the max plane index in the high half of a dword;
+// a ray that runs against the axis swaps the halves (one rotate by `rot`), so that the low half is always the
+// plane the ray enters through and no per-axis min/max is needed.
 // `stack` points at this lane's slot of the LDS stack; entries are `stride` ints apart.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float slab_rcp(float d) {
@@ -258,6 +262,7 @@ struct Trav {
     int sp;           // stack entries in use
     Best best;
     V3 ga, gb;        // slab test constants of the ray on the current BVH's grid: plane q lies at t = q * ga + gb
+    uint32_t rx, ry, rz;  // 16 where the ray runs against the axis (ga < 0), else 0: rotate count of a node's plane pair
     V3 ro, rd;        // ray in the current space (instanced scenes only; otherwise the world ray is used)
     uint32_t id_base; // id offset of the instance being traversed
     int32_t cur_inst; // instance record being traversed, -1 at top level
@@ -267,6 +272,16 @@ __device__ __forceinline__ void trav_set_ray(Trav& T, V3 o, V3 d, const float* g
     const V3 inv = slab_reciprocal(d);
     T.ga = v3(grid_step[0] * inv.x, grid_step[1] * inv.y, grid_step[2] * inv.z);
     T.gb = v3((grid_origin[0] - o.x) * inv.x, (grid_origin[1] - o.y) * inv.y, (grid_origin[2] - o.z) * inv.z);
+    T.rx = (__float_as_uint(inv.x) >> 31) << 4;
+    T.ry = (__float_as_uint(inv.y) >> 31) << 4;
+    T.rz = (__float_as_uint(inv.z) >> 31) << 4;
+}
+
+// (entry plane distance, exit plane distance) of one axis of a child box: `w` holds (min index | max index << 16)
+__device__ __forceinline__ void slab_pair(uint32_t w, uint32_t rot, float a, float b, float& t_in, float& t_out) {
+    const uint32_t v = __builtin_amdgcn_alignbit(w, w, rot);
+    t_in = __builtin_fmaf((float)(v & 0xFFFFu), a, b);
+    t_out = __builtin_fmaf((float)(v >> 16), a, b);
 }
 
 template <bool INST>
@@ -288,8 +303,8 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
 template <bool INST, bool COUNT>
 __device__ __forceinline__ void trav_nodes(const SceneDev& S, float tmin, int* stack, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes) {
-    const float far_scale = 1.000001f;
     const V3 ga = T.ga, gb = T.gb;
+    const uint32_t rx = T.rx, ry = T.ry, rz = T.rz;
     int cur = T.cur, sp = T.sp;
     while (cur >= 0) {
         const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
@@ -298,20 +313,19 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, float tmin, int* s
             cnt.nodes++;
             if (first_active_lane()) cnt.wave_nodes++;
         }
+        float ix, iy, iz, ox, oy, oz;
         // left box
-        float t0x = __builtin_fmaf((float)(a.z & 0xFFFFu), ga.x, gb.x), t1x = __builtin_fmaf((float)(a.z >> 16), ga.x, gb.x);
-        float t0y = __builtin_fmaf((float)(a.w & 0xFFFFu), ga.y, gb.y), t1y = __builtin_fmaf((float)(a.w >> 16), ga.y, gb.y);
-        float t0z = __builtin_fmaf((float)(b.x & 0xFFFFu), ga.z, gb.z), t1z = __builtin_fmaf((float)(b.x >> 16), ga.z, gb.z);
-        float ln = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-        float lf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
-        lf = fminf(lf, T.best.t);
+        slab_pair(a.z, rx, ga.x, gb.x, ix, ox);
+        slab_pair(a.w, ry, ga.y, gb.y, iy, oy);
+        slab_pair(b.x, rz, ga.z, gb.z, iz, oz);
+        const float ln = fmaxf(fmaxf(fmaxf(ix, iy), iz), tmin);
+        const float lf = fminf(fminf(fminf(ox, oy), oz), T.best.t);
         // right box
-        t0x = __builtin_fmaf((float)(b.y & 0xFFFFu), ga.x, gb.x); t1x = __builtin_fmaf((float)(b.y >> 16), ga.x, gb.x);
-        t0y = __builtin_fmaf((float)(b.z & 0xFFFFu), ga.y, gb.y); t1y = __builtin_fmaf((float)(b.z >> 16), ga.y, gb.y);
-        t0z = __builtin_fmaf((float)(b.w & 0xFFFFu), ga.z, gb.z); t1z = __builtin_fmaf((float)(b.w >> 16), ga.z, gb.z);
-        float rn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-        float rf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)) * far_scale;
-        rf = fminf(rf, T.best.t);
+        slab_pair(b.y, rx, ga.x, gb.x, ix, ox);
+        slab_pair(b.z, ry, ga.y, gb.y, iy, oy);
+        slab_pair(b.w, rz, ga.z, gb.z, iz, oz);
+        const float rn = fmaxf(fmaxf(fmaxf(ix, iy), iz), tmin);
+        const float rf = fminf(fminf(fminf(ox, oy), oz), T.best.t);
         const bool hl = ln <= lf, hr = rn <= rf;
         int left = (int)a.x, right = (int)a.y;
         if (hl && hr) {

@@ -15,18 +15,28 @@ uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp);
 // Share (in 64ths) of the walking lanes that must be descending for a node pass to run; 40/64 measured best
 // on MI355X for both the 968-triangle and the 1M-triangle scene.
 static constexpr uint32_t DEFAULT_NODE_SHARE_64THS = 40u;
+// Idle lanes of a wavefront that make the streaming ray-batch kernel draw new rays.
+static constexpr uint32_t DEFAULT_REFILL_MIN = 16u;
 
-// d_counters: 6 x u64 in device memory {rays, node visits, primitive tests, wave-level node passes, primitive
-//             passes, shading passes}; the kernel ADDS to them.
+// Scheduling parameters of the traversal kernels.
+struct RenderTuning {
+    uint32_t node_share_64ths = DEFAULT_NODE_SHARE_64THS;
+    uint32_t refill_min = DEFAULT_REFILL_MIN;
+};
+
+// d_counters: 7 x u64 in device memory {rays, node visits, primitive tests, wave-level node passes, primitive
+//             passes, shading passes, refill passes}; the kernels ADD to them.
 // d_heads:    8 x u32 work-queue heads, zero before the launch.
 // n_chunks > 1: the kernel writes n_chunks partial images (each width*height*3 floats) to d_partial and a second
 // kernel sums them into d_accum in chunk order; n_chunks == 1: the kernel writes d_accum directly.
 hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
                          float* d_accum, float* d_partial, uint32_t n_chunks, unsigned long long* d_counters,
-                         unsigned int* d_heads, int cu_count, bool count_visits, uint32_t node_share_64ths,
+                         unsigned int* d_heads, int cu_count, bool count_visits, const RenderTuning& tuning,
                          hipStream_t stream);
+// d_head: one u32, zero before the launch (the batch's ray counter).
 hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, float tmin, float tmax, rrt_hit* d_out,
-                            hipStream_t stream);
+                            unsigned long long* d_counters, unsigned int* d_head, int cu_count, bool count_visits,
+                            const RenderTuning& tuning, hipStream_t stream);
 hipError_t launch_tonemap(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb8,
                           hipStream_t stream);
 

@@ -18,6 +18,7 @@ namespace rrt {
 
 static constexpr int WAVE = 64;
 static constexpr int RENDER_BLOCK = 256;  // 4 independent wavefronts per workgroup
+static constexpr uint32_t TRACE_BLOCK = 512;  // ray indices a wavefront of the streaming kernel draws at a time
 static constexpr uint32_t N_QUEUES = 8;   // workgroup ids congruent mod 8 are dealt to one XCD and share its L2
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -170,20 +171,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 5) void k_render(SceneDev 
     if (lane == 0) atomicAdd(&counters[0], rays);
 }
 
-// Closest hit for a batch of rays: one lane per ray.  Sphere uv follows the reference's
-// get_sphere_uv (src/geometry/sphere.rs:34-40), including its far-root call with the un-normalised p.
-template <bool INST>
-__global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* __restrict__ rays, size_t n, float tmin,
-                                                    float tmax, rrt_hit* __restrict__ out) {
-    __shared__ int s_stack[STACK_DEPTH * WAVE];
-    const size_t i = (size_t)blockIdx.x * WAVE + threadIdx.x;
-    if (i >= n) return;
-    const rrt_ray r = rays[i];
-    const V3 o = v3(r.origin[0], r.origin[1], r.origin[2]);
-    const V3 d = v3(r.direction[0], r.direction[1], r.direction[2]);
-    Best best;
-    TraceCounters cnt = {0u, 0u, 0u, 0u, 0u};
-    trace<INST, false>(S, o, d, tmin, tmax, s_stack + threadIdx.x, WAVE, best, cnt);
+// The caller-visible record of a closest hit.  Sphere uv follows the reference's get_sphere_uv
+// (src/geometry/sphere.rs:34-40), including its far-root call with the un-normalised p.
+__device__ __forceinline__ rrt_hit hit_record(const SceneDev& S, const Best& best, V3 o, V3 d) {
     rrt_hit h;
     if (best.id == 0xFFFFFFFFu) {
         h.prim_id = -1; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f;
@@ -208,7 +198,101 @@ __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* _
             h.v = theta / RRT_PI;
         }
     }
-    out[i] = h;
+    return h;
+}
+
+// Closest hit for a batch of rays, one lane per ray from start to end (kept as the plain form of the walk; the
+// streaming kernel below is the one the library launches).
+template <bool INST>
+__global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* __restrict__ rays, size_t n, float tmin,
+                                                    float tmax, rrt_hit* __restrict__ out) {
+    __shared__ int s_stack[STACK_DEPTH * WAVE];
+    const size_t i = (size_t)blockIdx.x * WAVE + threadIdx.x;
+    if (i >= n) return;
+    const rrt_ray r = rays[i];
+    const V3 o = v3(r.origin[0], r.origin[1], r.origin[2]);
+    const V3 d = v3(r.direction[0], r.direction[1], r.direction[2]);
+    Best best;
+    TraceCounters cnt = {0u, 0u, 0u, 0u, 0u};
+    trace<INST, false>(S, o, d, tmin, tmax, s_stack + threadIdx.x, WAVE, best, cnt);
+    out[i] = hit_record(S, best, o, d);
+}
+
+// Closest hit for a batch of rays, streaming form: a persistent grid in which every lane takes the next ray of
+// the batch as soon as its own walk is complete, so that the lanes of a wavefront stay busy although their rays
+// need different numbers of steps.  Rays are handed out through one counter (`head`, zero before the launch) in
+// blocks of TRACE_BLOCK indices per wavefront (one atomic add per block: a counter shared by all eight XCDs takes
+// about 10 ns per add, which would otherwise bound the kernel); whenever at least `refill_min` lanes of a
+// wavefront are idle, they take the next indices of the wavefront's block.  counters (COUNT only): {-, node visits, primitive tests, node passes, primitive
+// passes, -, refill passes}.
+template <bool INST, bool COUNT>
+__global__ __launch_bounds__(RENDER_BLOCK, 5) void k_trace_stream(SceneDev S, const rrt_ray* __restrict__ rays, uint32_t n,
+                                                                  float tmin, float tmax, rrt_hit* __restrict__ out,
+                                                                  unsigned int* __restrict__ head, uint32_t refill_min,
+                                                                  uint32_t node_share_64ths,
+                                                                  unsigned long long* __restrict__ counters) {
+    __shared__ int s_stack[STACK_DEPTH * RENDER_BLOCK];
+    int* stack = s_stack + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t mine = 0xFFFFFFFFu;  // index of the ray this lane is walking (or has walked and not yet written)
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
+    Trav T;
+    T.cur = REF_DONE;
+    T.sp = 1;
+    TraceCounters cnt = {0u, 0u, 0u, 0u, 0u};
+    bool exhausted = false;  // wave-uniform: the batch has no rays left to hand out
+    uint32_t blk = 0u, blk_end = 0u;  // wave-uniform: the block of ray indices this wavefront hands to its lanes
+    for (;;) {
+        const bool idle = T.cur == REF_DONE;
+        const unsigned long long idle_m = __ballot(idle);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_m);
+        if ((!exhausted && n_idle >= refill_min) || n_idle == 64u) {
+            if (COUNT && lane == 0u) cnt.wave_shade++;
+            if (idle && mine != 0xFFFFFFFFu) {
+                out[mine] = hit_record(S, T.best, o, d);
+                mine = 0xFFFFFFFFu;
+            }
+            if (exhausted) break;  // every lane is idle and nothing is left
+            if (blk == blk_end) {  // the wavefront's private block is used up: draw the next one
+                unsigned int b = 0;
+                if (lane == 0u) b = atomicAdd(head, TRACE_BLOCK);
+                b = __shfl(b, 0, WAVE);
+                blk = b < n ? b : n;
+                blk_end = (unsigned long long)b + TRACE_BLOCK < n ? b + TRACE_BLOCK : n;
+                if (blk == blk_end) {
+                    exhausted = true;
+                    continue;
+                }
+            }
+            const uint32_t take = min(n_idle, blk_end - blk);
+            const uint32_t rank = (uint32_t)__popcll(idle_m & ((1ull << lane) - 1ull));
+            if (idle && rank < take) {
+                mine = blk + rank;
+                const rrt_ray r = rays[mine];
+                o = v3(r.origin[0], r.origin[1], r.origin[2]);
+                d = v3(r.direction[0], r.direction[1], r.direction[2]);
+                trav_begin<INST>(S, o, d, tmax, stack, T);
+            }
+            blk += take;
+            continue;
+        }
+        const uint32_t n_walk = 64u - n_idle;
+        const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
+        const uint32_t share = (n_walk * node_share_64ths) >> 6;
+        if (n_desc == n_walk || n_desc >= share) trav_nodes<INST, COUNT>(S, tmin, stack, RENDER_BLOCK, T, cnt, share);
+        if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stack, RENDER_BLOCK, T, cnt);
+    }
+    if (COUNT) {
+        const unsigned long long nn = wave_sum((unsigned long long)cnt.nodes);
+        const unsigned long long np = wave_sum((unsigned long long)cnt.prims);
+        const unsigned long long wn = wave_sum((unsigned long long)cnt.wave_nodes);
+        const unsigned long long wp = wave_sum((unsigned long long)cnt.wave_prims);
+        const unsigned long long wr = wave_sum((unsigned long long)cnt.wave_shade);
+        if (lane == 0u) {
+            atomicAdd(&counters[1], nn); atomicAdd(&counters[2], np);
+            atomicAdd(&counters[3], wn); atomicAdd(&counters[4], wp); atomicAdd(&counters[6], wr);
+        }
+    }
 }
 
 // get_color + flipped put_pixel -- reference src/vec3.rs:30-53, src/main.rs:104-109
@@ -284,7 +368,7 @@ static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, 
 
 hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
                          float* d_accum, float* d_partial, uint32_t n_chunks, unsigned long long* d_counters,
-                         unsigned int* d_heads, int cu_count, bool count_visits, uint32_t node_share_64ths,
+                         unsigned int* d_heads, int cu_count, bool count_visits, const RenderTuning& tuning,
                          hipStream_t stream) {
     RenderGeom G;
     G.width = width; G.height = height; G.spp = spp; G.spp_offset = spp_offset;
@@ -293,7 +377,7 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     G.n_chunks = n_chunks;
     G.chunk_spp = (spp + n_chunks - 1u) / n_chunks;
     G.n_work = G.n_tiles * G.n_chunks;
-    G.node_share_64ths = node_share_64ths;
+    G.node_share_64ths = tuning.node_share_64ths;
     float* out = n_chunks > 1u ? d_partial : d_accum;
     const bool inst = S.has_instances != 0u;
     hipError_t e;
@@ -307,15 +391,43 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     return hipGetLastError();
 }
 
-hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, float tmin, float tmax, rrt_hit* d_out,
-                            hipStream_t stream) {
-    if (n == 0) return hipSuccess;
-    dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
-    if (S.has_instances)
-        hipLaunchKernelGGL((k_intersect<true>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
-    else
-        hipLaunchKernelGGL((k_intersect<false>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
+template <bool INST, bool COUNT>
+static hipError_t launch_trace_variant(const SceneDev& S, const rrt_ray* d_rays, uint32_t n, float tmin, float tmax,
+                                       rrt_hit* d_out, unsigned long long* d_counters, unsigned int* d_head, int cu_count,
+                                       const RenderTuning& tuning, hipStream_t stream) {
+    static int blocks_per_cu = 0;  // per template instantiation
+    if (blocks_per_cu == 0) {
+        int k = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_trace_stream<INST, COUNT>, RENDER_BLOCK, 0);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = k > 0 ? k : 1;
+    }
+    unsigned long long blocks = (unsigned long long)blocks_per_cu * (unsigned)cu_count;
+    const unsigned long long needed = ((unsigned long long)n + RENDER_BLOCK - 1ull) / RENDER_BLOCK;
+    if (blocks > needed) blocks = needed;
+    hipLaunchKernelGGL((k_trace_stream<INST, COUNT>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, d_rays, n, tmin,
+                       tmax, d_out, d_head, tuning.refill_min, tuning.node_share_64ths, d_counters);
     return hipGetLastError();
+}
+
+hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, float tmin, float tmax, rrt_hit* d_out,
+                            unsigned long long* d_counters, unsigned int* d_head, int cu_count, bool count_visits,
+                            const RenderTuning& tuning, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (getenv("RRT_INTERSECT_STATIC")) {  // experiment knob: the plain one-lane-per-ray kernel
+        dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
+        if (S.has_instances)
+            hipLaunchKernelGGL((k_intersect<true>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
+        else
+            hipLaunchKernelGGL((k_intersect<false>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
+        return hipGetLastError();
+    }
+    const bool inst = S.has_instances != 0u;
+    const uint32_t m = (uint32_t)n;
+    if (inst && count_visits) return launch_trace_variant<true, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+    if (inst) return launch_trace_variant<true, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+    if (count_visits) return launch_trace_variant<false, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+    return launch_trace_variant<false, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
 }
 
 hipError_t launch_tonemap(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb8,

@@ -27,6 +27,8 @@ def main():
     scene, w, h, spp, name = bench.build_scene(rrt, args.config)
     r = rrt.Renderer()
     r.upload(scene)
+    rc = rrt.Renderer(count_visits=True)
+    rc.upload(scene)
     o = oracle.OracleScene(scene)
     g = np.random.default_rng(1)
     n = args.rays
@@ -52,7 +54,13 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         hits = d_hits.cpu().numpy().view(rrt.HIT_DTYPE)
-        print(f"{label}: {len(rays)} rays {ms:.3f} ms {len(rays) / ms / 1e3:.0f} Mrays/s hit rate {(hits['prim_id'] >= 0).mean():.3f}", flush=True)
+        rc.intersect_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), stream=stream.cuda_stream)
+        st = rc.render_stats()
+        n = len(rays)
+        print(f"{label}: {n} rays {ms:.3f} ms {n / ms / 1e3:.0f} Mrays/s hit rate {(hits['prim_id'] >= 0).mean():.3f}"
+              f" nodes/ray {st.node_visits / n:.1f} prims/ray {st.prim_tests / n:.2f}"
+              f" lane util node {st.node_visits / max(64 * st.node_wave_steps, 1):.3f} prim {st.prim_tests / max(64 * st.prim_wave_steps, 1):.3f}"
+              f" refills/ray {st.refill_wave_passes / n:.4f}", flush=True)
         return hits
 
     hits = run(prim, "primary (tile order)")
@@ -65,6 +73,15 @@ def main():
     bounce["origin"], bounce["direction"] = p + d * 1e-3, d
     run(bounce, "bounce (same order)")
     run(bounce[g.permutation(len(bounce))], "bounce (shuffled)")
+    # the mix a path tracer's ray queue holds: primary and bounce rays, in runs of 64 and ray by ray
+    m = min(len(prim), len(bounce)) // 64 * 64
+    mixed = np.empty(2 * m, rrt.RAY_DTYPE)
+    mixed.reshape(-1, 2, 64)[:, 0, :] = prim[:m].reshape(-1, 64)
+    mixed.reshape(-1, 2, 64)[:, 1, :] = bounce[:m].reshape(-1, 64)
+    run(mixed, "primary + bounce, runs of 64")
+    mixed[0::2] = prim[:m]
+    mixed[1::2] = bounce[:m]
+    run(mixed, "primary + bounce, alternating")
 
 
 if __name__ == "__main__":
