@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the path-tracing hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config 2|1|4] [--spp S]
+    python bench.py --gpus N --steps K --warmup W [--config 4|1|2|3|5] [--spp S]
+
+The default workload is the one the headline target is quoted on: the synthetic 1,048,576-triangle mesh at
+3840x2160 with 128 samples per pixel per GPU, so that 8 GPUs render the 4K x 1024 spp frame of that target and one GPU
+renders its eighth of the samples.  `--config 2` is the single-GPU asset case (suzanne, 1080p, 256 spp).
 
 One *step* = one full pass of the hot path over one frame: render kernel (camera rays -> closest hit ->
 scatter -> bounce, `spp` samples per pixel), the RCCL reduce of the radiance accumulation buffers to rank 0
@@ -92,10 +96,11 @@ def cpu_baseline(scene, width, height, spp_full, seed, budget_s=15.0):
             "samples_per_s": sw * sh * spp / dt}
 
 
-def measured_traffic(config: int, width: int, height: int, spp: int):
-    """HBM bytes per k_render launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json, written from
-    tools/prof.sh output); None when this exact workload has not been profiled."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def measured_pmc(config: int, width: int, height: int, spp: int):
+    """Per-launch hardware-counter figures of k_render from the committed rocprofv3 PMC passes
+    (profiles/pmc_per_launch.json, written from tools/prof.sh output); None when this exact workload has not been
+    profiled."""
+    path = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
     try:
         with open(path) as f:
             row = json.load(f).get(str(config))
@@ -103,7 +108,13 @@ def measured_traffic(config: int, width: int, height: int, spp: int):
         return None
     if not row or (row["width"], row["height"], row["spp_per_gpu"]) != (width, height, spp):
         return None
-    return float(row["bytes_per_launch"])
+    return row
+
+
+# Issue time of one wave-instruction on one SIMD for the classes the traversal loop is made of, measured with
+# tools/valu_peak.hip at 4 waves per SIMD (profiles/round1_valu_issue_rate_mi355x.txt).  v_fma_f32 is the fastest class.
+VALU_NS_FMA = 3.06 / 2.4
+VALU_NS_SELECT_CLASS = 4.3 / 2.4  # min/max/min3/max3, sub-dword converts, compare + select
 
 
 def main():
@@ -111,7 +122,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (default: the config's)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,9 +205,10 @@ def main():
         bytes_per_ray = nodes_per_ray * NODE_BYTES + prims_per_ray * PRIM_BYTES
         algo_bytes = rays_per_step * bytes_per_ray + width * height * 12.0
         k_ms = float(np.mean(kernel_ms))
+        pmc = measured_pmc(args.config, width, height, spp)
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.config, width, height, spp), "kernel": "k_render", "kernel_ms": k_ms, "nodes_per_ray": nodes_per_ray,
+                "traffic": float(pmc["hbm_bytes"]) if pmc else None, "kernel": "k_render", "kernel_ms": k_ms, "nodes_per_ray": nodes_per_ray,
                 "prims_per_ray": prims_per_ray, "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_step,
                 "samples_per_launch": samples,
                 # fraction of the 64 lanes doing useful work in a node step / primitive test / shading pass
@@ -205,6 +217,14 @@ def main():
                 "lane_util_shade": cs.rays / max(64 * cs.shade_wave_passes, 1),
                 "wave_steps_per_ray": {"node": 64 * cs.node_wave_steps / max(cs.rays, 1), "prim": 64 * cs.prim_wave_steps / max(cs.rays, 1),
                                        "shade": 64 * cs.shade_wave_passes / max(cs.rays, 1)}}
+        if pmc and "sq_insts_valu" in pmc:
+            per_simd = pmc["sq_insts_valu"] / pmc["simds"]
+            # the kernel is bound by vector-ALU issue, not by HBM: share of the launch a SIMD spends issuing VALU
+            # instructions, priced at the fastest class (lower bound) and at the class most of the loop belongs to
+            roof["valu"] = {"insts_per_ray": pmc["sq_insts_valu"] / rays_per_step,
+                            "issue_frac_at_fma_rate": per_simd * VALU_NS_FMA * 1e-6 / k_ms,
+                            "issue_frac_at_select_rate": per_simd * VALU_NS_SELECT_CLASS * 1e-6 / k_ms,
+                            "source": "profiles/pmc_per_launch.json (rocprofv3 --pmc SQ_INSTS_VALU), tools/valu_peak.hip"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene, width, height, spp, args.seed)
 
