@@ -158,3 +158,39 @@ def test_api_errors(rrt):
     with pytest.raises(rrt.RrtError):
         rrt.Renderer(max_depth=0)
     r.close()
+
+
+def test_streaming_batch_sizes_order_and_counters(rrt, oracle, renderer_cache, monkeypatch):
+    """The batch kernel hands ray indices to wavefronts in blocks of 512 and to lanes as they fall idle: results must
+    not depend on the batch size relative to the block, on the order of the rays, or on the refill threshold."""
+    r, scene = get(rrt, renderer_cache, "synthetic")
+    o = oracle.OracleScene(scene)
+    base = helpers.primary_rays(o, 160, 90, 4096, seed=9)
+    want = o.intersect(base)
+    for n in (511, 512, 513, 1023, 1025, 4096):
+        helpers.assert_hits_match(r.intersect(base[:n]), want[:n])
+    perm = np.random.default_rng(4).permutation(len(base))
+    assert np.array_equal(r.intersect(base[perm]), r.intersect(base)[perm])
+    # many more rays than the resident grid holds lanes: every wavefront draws several blocks
+    big = np.tile(base, 700)[: 512 * 5120 + 7]
+    got = r.intersect(big)
+    ref = np.tile(r.intersect(base), 700)[: len(big)]
+    assert np.array_equal(got, ref)
+    # refill threshold 1 (every idle lane refills at once) and 64 (a wave only refills when it is empty)
+    for thr in ("1", "64"):
+        monkeypatch.setenv("RRT_REFILL_MIN", thr)
+        assert np.array_equal(r.intersect(base), ref[: len(base)])
+    monkeypatch.delenv("RRT_REFILL_MIN")
+    # the plain one-lane-per-ray kernel is the same function of the rays
+    monkeypatch.setenv("RRT_INTERSECT_STATIC", "1")
+    assert np.array_equal(r.intersect(base), ref[: len(base)])
+    monkeypatch.delenv("RRT_INTERSECT_STATIC")
+    # counting variant: same hits, counters consistent with the walk
+    rc = rrt.Renderer(count_visits=True)
+    rc.upload(scene)
+    assert np.array_equal(rc.intersect(base), ref[: len(base)])
+    st = rc.render_stats()
+    assert st.rays == len(base) and st.samples == 0
+    assert st.node_visits >= st.rays and st.node_wave_steps * 64 >= st.node_visits
+    assert st.prim_wave_steps * 64 >= st.prim_tests > 0 and st.refill_wave_passes > 0
+    rc.close()
