@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU (default: the config's)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device-build", action="store_true", help="build large BVHs on the GPU (linear BVH) instead of the host's SAH build")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,7 +148,7 @@ def main():
     spp_total = spp * world
     spp_offset = rank * spp
 
-    renderer = rrt.Renderer(device=local_rank, seed=args.seed)
+    renderer = rrt.Renderer(device=local_rank, seed=args.seed, device_build=args.device_build)
     info = renderer.upload(scene)
     accum = torch.empty((height, width, 3), dtype=torch.float32, device=device)
     rgb8 = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
@@ -193,7 +194,7 @@ def main():
     roof = None
     cpu = None
     if rank == 0:
-        counting = rrt.Renderer(device=local_rank, seed=args.seed, count_visits=True)
+        counting = rrt.Renderer(device=local_rank, seed=args.seed, count_visits=True, device_build=args.device_build)
         counting.upload(scene)
         probe_spp = min(spp, 8)
         counting.render_device(width, height, probe_spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
@@ -237,7 +238,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.config >= 4 else "reference asset (bundled glTF), random-free scene; counter-RNG seed %d" % args.seed,
             "config": {"workload": workload, "width": width, "height": height, "spp_per_gpu": spp, "spp_total": spp_total,
                        "max_depth": 4, "prims": info.prim_count, "bvh_nodes": info.node_count, "bvh_depth": info.bvh_depth,
-                       "scene_bytes": info.device_bytes, "bvh_build_ms": info.build_ms, "partition": "spp slices per GPU + RCCL reduce(sum) to rank 0"},
+                       "scene_bytes": info.device_bytes, "bvh_build_ms": info.build_ms,
+                       "bvh_builder": "gpu linear BVH" if info.device_built else "host binned SAH", "partition": "spp slices per GPU + RCCL reduce(sum) to rank 0"},
             "samples_per_s": width * height * spp * world * args.steps / elapsed,
             "rays_per_sample": rays_all / (width * height * spp * world),
             "roofline": roof,

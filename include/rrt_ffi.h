@@ -61,6 +61,9 @@ typedef struct rrt_config {
 } rrt_config;
 #define RRT_CFG_DEFAULT 0u
 #define RRT_CFG_COUNT_VISITS 1u /* also count BVH node visits / primitive tests (slower kernel variant) */
+#define RRT_CFG_DEVICE_BUILD 2u /* build large BVHs (>= 4096 primitives) on the GPU: a linear BVH over Morton-sorted
+                                 * primitives instead of the host's SAH build (reference src/geometry/mod.rs:161-199 is
+                                 * the step it replaces).  Faster to build, slower to traverse; results are identical. */
 
 /* ---- scene description: the reference's scene/material types as POD ---- */
 
@@ -193,8 +196,10 @@ typedef struct rrt_scene_info {
     uint32_t tri_count;      /* triangle records in HBM                                   */
     uint32_t bvh_depth;      /* deepest leaf (top level + bottom level for instances)     */
     uint64_t device_bytes;   /* bytes of HBM the scene occupies                           */
-    float build_ms;          /* host BVH build                                            */
+    float build_ms;          /* BVH build (host, plus the GPU builder where it ran)       */
     float upload_ms;
+    uint32_t device_built;   /* number of BVHs the GPU builder built                      */
+    uint32_t reserved;
 } rrt_scene_info;
 
 /* ---- lifetime ----  replaces: process start-up in reference src/main.rs:26-56 */

@@ -30,6 +30,7 @@ OBJ_TRIANGLES, OBJ_SPHERES, OBJ_RECTS, OBJ_CUBOIDS, OBJ_INSTANCE = 0, 1, 2, 3, 4
 LIGHT_SPHERE, LIGHT_XZRECT, LIGHT_OTHER = 0, 1, 2
 RECT_FLIP_FACE = 1
 CFG_COUNT_VISITS = 1
+CFG_DEVICE_BUILD = 2
 GLTF_COMPAT, GLTF_EXTENDED = 0, 1
 
 
@@ -122,7 +123,7 @@ class Stats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("prim_count", C.c_uint32), ("node_count", C.c_uint32), ("tri_count", C.c_uint32),
                 ("bvh_depth", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
-                ("upload_ms", C.c_float)]
+                ("upload_ms", C.c_float), ("device_built", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GltfOptions(C.Structure):
@@ -455,9 +456,11 @@ class Renderer:
     ``BVHNode::new`` (src/gltf.rs:343), ``render`` for the pixel loop (src/main.rs:86-103), ``tonemap`` for
     ``get_color`` + ``put_pixel`` (src/vec3.rs:30-53, src/main.rs:104-109)."""
 
-    def __init__(self, device: int = 0, seed: int = 1, max_depth: int = 4, t_min: float = 1e-4, count_visits: bool = False):
+    def __init__(self, device: int = 0, seed: int = 1, max_depth: int = 4, t_min: float = 1e-4, count_visits: bool = False,
+                 device_build: bool = False):
         self.lib = load_library()
-        cfg = Config(device, seed, max_depth, t_min, CFG_COUNT_VISITS if count_visits else 0)
+        cfg = Config(device, seed, max_depth, t_min,
+                     (CFG_COUNT_VISITS if count_visits else 0) | (CFG_DEVICE_BUILD if device_build else 0))
         self.ctx = C.c_void_p()
         _check(self.lib.rrt_create(C.byref(cfg), C.byref(self.ctx)), None)
         self._scene_keep = None

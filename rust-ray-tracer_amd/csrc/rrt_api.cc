@@ -11,6 +11,7 @@
 
 #include "../../include/rrt_ffi.h"
 #include "rrt_internal.h"
+#include "lbvh_build.h"
 #include "rrt_kernels.h"
 #include "scene_build.h"
 
@@ -141,31 +142,72 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     if (!c) return set_err(nullptr, RRT_ERR_INVALID, "rrt_scene_upload: ctx is NULL");
     if (!scene) return set_err(c, RRT_ERR_INVALID, "rrt_scene_upload: scene is NULL");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
+    // BVHs over at least this many primitives are built on the GPU when the context asks for it
+    uint32_t device_min = 0;
+    if (c->cfg.flags & RRT_CFG_DEVICE_BUILD) {
+        device_min = 4096;
+        if (const char* e = std::getenv("RRT_DEVICE_BUILD_MIN")) device_min = (uint32_t)std::max(2, std::atoi(e));
+    }
     HostScene hs;
     std::string err;
-    const auto t0 = std::chrono::steady_clock::now();
     rrt_status st;
-    try {
-        st = build_host_scene(scene, hs, err, build_threads());
-    } catch (const std::bad_alloc&) {
-        return set_err(c, RRT_ERR_OOM, "rrt_scene_upload: out of host memory while building the BVH");
-    } catch (const std::exception& ex) {
-        return set_err(c, RRT_ERR_INVALID, std::string("rrt_scene_upload: ") + ex.what());
-    }
-    if (st != RRT_OK) return set_err(c, st, "rrt_scene_upload: " + err);
-    const auto t1 = std::chrono::steady_clock::now();
-
-    RRT_HIP(c, hipDeviceSynchronize());
-    free_scene(c);
     uint64_t total = 0;
-    if ((st = upload(c, hs.qnodes, &c->d_nodes, total)) != RRT_OK || (st = upload(c, hs.tris, &c->d_tris, total)) != RRT_OK ||
-        (st = upload(c, hs.spheres, &c->d_spheres, total)) != RRT_OK || (st = upload(c, hs.rects, &c->d_rects, total)) != RRT_OK ||
-        (st = upload(c, hs.insts, &c->d_insts, total)) != RRT_OK || (st = upload(c, hs.mats, &c->d_mats, total)) != RRT_OK ||
-        (st = upload(c, hs.lights, &c->d_lights, total)) != RRT_OK) {
+    float build_ms = 0.f, upload_ms = 0.f;
+    for (;;) {
+        const auto t0 = std::chrono::steady_clock::now();
+        try {
+            st = build_host_scene(scene, hs, err, build_threads(), device_min);
+        } catch (const std::bad_alloc&) {
+            return set_err(c, RRT_ERR_OOM, "rrt_scene_upload: out of host memory while building the BVH");
+        } catch (const std::exception& ex) {
+            return set_err(c, RRT_ERR_INVALID, std::string("rrt_scene_upload: ") + ex.what());
+        }
+        if (st != RRT_OK) return set_err(c, st, "rrt_scene_upload: " + err);
+        const auto t1 = std::chrono::steady_clock::now();
+
+        RRT_HIP(c, hipDeviceSynchronize());
         free_scene(c);
-        return st;
+        total = 0;
+        if ((st = upload(c, hs.qnodes, &c->d_nodes, total)) != RRT_OK || (st = upload(c, hs.tris, &c->d_tris, total)) != RRT_OK ||
+            (st = upload(c, hs.spheres, &c->d_spheres, total)) != RRT_OK || (st = upload(c, hs.rects, &c->d_rects, total)) != RRT_OK ||
+            (st = upload(c, hs.insts, &c->d_insts, total)) != RRT_OK || (st = upload(c, hs.mats, &c->d_mats, total)) != RRT_OK ||
+            (st = upload(c, hs.lights, &c->d_lights, total)) != RRT_OK) {
+            free_scene(c);
+            return st;
+        }
+        const auto t2 = std::chrono::steady_clock::now();
+
+        // the BVHs left to the GPU builder (none unless the context was created with RRT_CFG_DEVICE_BUILD)
+        bool fits = true;
+        for (const DeferredBuild& db : hs.deferred) {
+            LbvhResult r;
+            // a mesh may use every level the (already built) top level leaves free
+            const uint32_t budget = db.mesh >= 0 && hs.top_depth > 0u && hs.top_depth + 2u <= MAX_TREE_DEPTH
+                                        ? MAX_TREE_DEPTH - hs.top_depth - 1u : db.budget;
+            const hipError_t e = lbvh_build(db.prims.data(), (uint32_t)db.prims.size(), db.grid, (QNode*)c->d_nodes, db.node_base,
+                                            (TriRec*)c->d_tris, db.tri_base, db.tri_count, budget, &r);
+            if (e != hipSuccess) {
+                free_scene(c);
+                return hip_fail(c, e, "rrt_scene_upload: GPU BVH build");
+            }
+            if (r.depth == 0u) { fits = false; break; }
+            if (db.mesh < 0) hs.top_depth = r.depth;
+            else hs.deepest_mesh = std::max(hs.deepest_mesh, r.depth);
+        }
+        if (fits && hs.top_depth + (hs.has_instances ? hs.deepest_mesh + 1u : 0u) > MAX_TREE_DEPTH) fits = false;
+        const auto t3 = std::chrono::steady_clock::now();
+        build_ms += std::chrono::duration<float, std::milli>(t1 - t0).count() + std::chrono::duration<float, std::milli>(t3 - t2).count();
+        upload_ms += std::chrono::duration<float, std::milli>(t2 - t1).count();
+        if (fits) break;
+        // a linear BVH deeper than the traversal stack allows: build everything with the depth-bounded host builder
+        if (device_min == 0u) {
+            free_scene(c);
+            return set_err(c, RRT_ERR_INVALID, "rrt_scene_upload: scene too deep for the traversal stack");
+        }
+        device_min = 0;
     }
-    const auto t2 = std::chrono::steady_clock::now();
+    hs.depth = hs.top_depth + (hs.has_instances ? hs.deepest_mesh : 0u);
+    c->info.device_built = (uint32_t)hs.deferred.size();
 
     SceneDev& S = c->sdev;
     S.nodes = (const QNode*)c->d_nodes; S.tris = (const TriRec*)c->d_tris; S.spheres = (const SphereRec*)c->d_spheres;
@@ -187,8 +229,8 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     c->info.tri_count = (uint32_t)hs.tris.size();
     c->info.bvh_depth = hs.depth;
     c->info.device_bytes = total;
-    c->info.build_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    c->info.upload_ms = std::chrono::duration<float, std::milli>(t2 - t1).count();
+    c->info.build_ms = build_ms;
+    c->info.upload_ms = upload_ms;
     c->has_scene = true;
     return RRT_OK;
 }

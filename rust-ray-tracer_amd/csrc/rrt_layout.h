@@ -12,7 +12,14 @@
 #ifndef RRT_LAYOUT_H
 #define RRT_LAYOUT_H
 
+#include <math.h>
 #include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RRT_HD __host__ __device__
+#else
+#define RRT_HD
+#endif
 
 namespace rrt {
 
@@ -29,7 +36,7 @@ static constexpr uint32_t MAX_LEAF_TRIS = 8u;
 static constexpr int32_t REF_DONE = (int32_t)(REF_LEAF | (KIND_DONE << 28));
 static constexpr int32_t REF_INST_EXIT = (int32_t)(REF_LEAF | (KIND_INST_EXIT << 28));
 
-static inline uint32_t make_leaf_ref(uint32_t kind, uint32_t first, uint32_t count) {
+RRT_HD static inline uint32_t make_leaf_ref(uint32_t kind, uint32_t first, uint32_t count) {
     return REF_LEAF | (kind << 28) | (((count - 1u) & 7u) << 25) | (first & REF_OFFSET_MASK);
 }
 
@@ -57,6 +64,21 @@ struct alignas(16) QNode {
     uint32_t rbox[3];         // right child
 };
 static_assert(sizeof(QNode) == 32, "QNode must be 32 bytes");
+
+// Plane indices of one child box [mn, mx] on grid g, rounded outwards by one extra plane: the stored box contains
+// the given one.  Used by the host builder and by the on-device builder alike.
+RRT_HD static inline void quantize_box(const Grid& g, const float* mn, const float* mx, uint32_t* out) {
+    for (int a = 0; a < 3; ++a) {
+        const double o = g.origin[a], s = g.step[a];
+        double qlo = floor(((double)mn[a] - o) / s) - 1.0;
+        double qhi = ceil(((double)mx[a] - o) / s) + 1.0;
+        if (!(qlo >= 0.0)) qlo = 0.0;          // also catches the NaN of an empty slot's sentinel box
+        if (!(qhi <= 65535.0)) qhi = 65535.0;
+        if (qlo > 65535.0) qlo = 65535.0;
+        if (qhi < 0.0) qhi = 0.0;
+        out[a] = (uint32_t)qlo | ((uint32_t)qhi << 16);
+    }
+}
 
 struct alignas(16) TriRec {
     float v0[3];   uint32_t id;

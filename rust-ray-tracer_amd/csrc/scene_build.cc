@@ -198,7 +198,9 @@ static float max_abs3(const float* v) {
 // Grid of 65536 planes per axis over a BVH's root box [mn, mx], with two steps of slack at the low end.  The step
 // is at least 2^-20 of the largest coordinate, so that rounding the origin to a float moves it by a small
 // fraction of a step.
-static Grid make_grid(const float* mn, const float* mx) {
+}  // namespace
+
+Grid make_grid(const float* mn, const float* mx) {
     Grid g;
     for (int a = 0; a < 3; ++a) {
         double lo = mn[a], hi = mx[a];
@@ -216,19 +218,7 @@ static Grid make_grid(const float* mn, const float* mx) {
     return g;
 }
 
-// Plane indices of one child box, rounded outwards by one extra plane: the stored box contains [mn, mx].
-static void quantize_box(const Grid& g, const float* mn, const float* mx, uint32_t* out) {
-    for (int a = 0; a < 3; ++a) {
-        const double o = g.origin[a], s = g.step[a];
-        double qlo = std::floor(((double)mn[a] - o) / s) - 1.0;
-        double qhi = std::ceil(((double)mx[a] - o) / s) + 1.0;
-        if (!(qlo >= 0.0)) qlo = 0.0;          // also catches the NaN of an empty slot's sentinel box
-        if (!(qhi <= 65535.0)) qhi = 65535.0;
-        if (qlo > 65535.0) qlo = 65535.0;
-        if (qhi < 0.0) qhi = 0.0;
-        out[a] = (uint32_t)qlo | ((uint32_t)qhi << 16);
-    }
-}
+namespace {
 
 // Appends the quantized form of hs.nodes[first..] (one BVH, root box [mn, mx]) to hs.qnodes.
 static Grid quantize_nodes(HostScene& hs, size_t first, const float* mn, const float* mx) {
@@ -247,7 +237,36 @@ static Grid quantize_nodes(HostScene& hs, size_t first, const float* mn, const f
 
 }  // namespace
 
-rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string& err, unsigned threads) {
+// Reserves nodes and triangle slots for a BVH the GPU will build; returns its root box in mn/mx.
+static void defer_build(HostScene& hs, std::vector<BuildPrim>& prims, std::vector<uint32_t>& tri_order, uint32_t budget,
+                        int mesh, float* mn, float* mx, int32_t& root, Grid& grid) {
+    DeferredBuild db;
+    db.node_base = (uint32_t)hs.nodes.size();
+    db.tri_base = (uint32_t)tri_order.size();
+    db.budget = budget;
+    db.mesh = mesh;
+    for (int a = 0; a < 3; ++a) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; }
+    uint32_t ordinal = 0;
+    for (BuildPrim& p : prims) {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p.bmin[a]); mx[a] = std::max(mx[a], p.bmax[a]); }
+        if (p.kind == KIND_TRI) {
+            tri_order.push_back(p.index);
+            p.index = ordinal++;
+        }
+    }
+    db.tri_count = ordinal;
+    db.grid = grid = make_grid(mn, mx);
+    BvhNode blank;
+    std::memset(&blank, 0, sizeof blank);
+    hs.nodes.resize(hs.nodes.size() + prims.size(), blank);
+    hs.qnodes.resize(hs.nodes.size());
+    root = (int32_t)db.node_base;  // the radix tree's root is its first inner node
+    db.prims.swap(prims);
+    hs.deferred.push_back(std::move(db));
+}
+
+rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string& err, unsigned threads,
+                            uint32_t device_build_min) {
     hs = HostScene();
     if (!d) { err = "scene is NULL"; return RRT_ERR_INVALID; }
     if (d->material_count == 0 || !d->materials) { err = "scene has no materials"; return RRT_ERR_INVALID; }
@@ -324,6 +343,12 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         uint32_t id = 0;
         if (!ex.expand(d->mesh_objects + m.first_object, m.object_count, id, prims, nullptr)) return RRT_ERR_INVALID;
         const uint32_t budget = MAX_TREE_DEPTH - top_budget - 1u;
+        if (device_build_min && prims.size() >= device_build_min) {
+            defer_build(hs, prims, tri_order, budget, (int)mi, meshes[mi].mn, meshes[mi].mx, meshes[mi].root, meshes[mi].grid);
+            meshes[mi].prim_count = id;
+            meshes[mi].depth = 0;
+            continue;
+        }
         const size_t first_node = hs.nodes.size();
         BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), budget, threads);
         meshes[mi].grid = quantize_nodes(hs, first_node, br.root_min, br.root_max);
@@ -339,16 +364,25 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     std::vector<BuildPrim> prims;
     uint32_t id = 0;
     if (!ex.expand(d->world, d->world_count, id, prims, &meshes)) return RRT_ERR_INVALID;
-    const size_t first_node = hs.nodes.size();
-    BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), top_budget, threads);
-    hs.grid = quantize_nodes(hs, first_node, br.root_min, br.root_max);
-    if (br.depth + (hs.insts.empty() ? 0u : deepest_mesh + 1u) > MAX_TREE_DEPTH) {
-        err = "scene too deep for the traversal stack";
-        return RRT_ERR_INVALID;
-    }
-    hs.root = br.root;
     hs.prim_count = id;
-    hs.depth = br.depth + (hs.insts.empty() ? 0u : deepest_mesh);
+    hs.deepest_mesh = deepest_mesh;
+    if (device_build_min && prims.size() >= device_build_min) {
+        float mn[3], mx[3];
+        defer_build(hs, prims, tri_order, top_budget, -1, mn, mx, hs.root, hs.grid);
+        hs.top_depth = 0;
+        hs.depth = 0;
+    } else {
+        const size_t first_node = hs.nodes.size();
+        BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), top_budget, threads);
+        hs.grid = quantize_nodes(hs, first_node, br.root_min, br.root_max);
+        if (br.depth + (hs.insts.empty() ? 0u : deepest_mesh + 1u) > MAX_TREE_DEPTH) {
+            err = "scene too deep for the traversal stack";
+            return RRT_ERR_INVALID;
+        }
+        hs.root = br.root;
+        hs.top_depth = br.depth;
+        hs.depth = br.depth + (hs.insts.empty() ? 0u : deepest_mesh);
+    }
     hs.has_instances = !hs.insts.empty();
     if (tri_order.size() > REF_OFFSET_MASK) { err = "too many triangles"; return RRT_ERR_INVALID; }
 

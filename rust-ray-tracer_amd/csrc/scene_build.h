@@ -6,9 +6,22 @@
 #include <vector>
 
 #include "../../include/rrt_ffi.h"
+#include "bvh_builder.h"
 #include "rrt_layout.h"
 
 namespace rrt {
+
+// A BVH whose construction is left to the GPU builder: its primitives (in submission order; a triangle's `index`
+// is its ordinal among this BVH's triangles, whose records start at tri_base in the same order), the node range
+// reserved for it (prims.size() nodes from node_base; the root is the first of them) and its grid.
+struct DeferredBuild {
+    std::vector<BuildPrim> prims;
+    uint32_t node_base = 0;
+    uint32_t tri_base = 0, tri_count = 0;
+    uint32_t budget = 0;   // node levels the BVH may have
+    int mesh = -1;         // mesh index, -1: the top-level BVH
+    Grid grid{};
+};
 
 struct HostScene {
     std::vector<BvhNode> nodes;   // builder output (full-precision boxes), host only
@@ -22,14 +35,22 @@ struct HostScene {
     std::vector<LightRec> lights;
     int32_t root = 0;
     uint32_t prim_count = 0;
-    uint32_t depth = 0;
+    uint32_t depth = 0;            // node levels of the deepest path (top level + deepest mesh)
+    uint32_t top_depth = 0;        // node levels of the top-level BVH (0 while its build is deferred)
+    uint32_t deepest_mesh = 0;     // node levels of the deepest host-built mesh BVH
+    std::vector<DeferredBuild> deferred;
     bool has_instances = false;
     CameraRec cam{};
     float background[3] = {0.f, 0.f, 0.f};
 };
 
 // Returns RRT_OK or RRT_ERR_INVALID with a message.  `threads` host threads are used for the BVH build.
-rrt_status build_host_scene(const rrt_scene_desc* desc, HostScene& out, std::string& err, unsigned threads);
+// device_build_min > 0: BVHs over at least that many primitives are not built here but listed in out.deferred.
+rrt_status build_host_scene(const rrt_scene_desc* desc, HostScene& out, std::string& err, unsigned threads,
+                            uint32_t device_build_min = 0);
+
+// Grid of 65536 planes per axis over the box [mn, mx] of a BVH's root.
+Grid make_grid(const float* mn, const float* mx);
 
 }  // namespace rrt
 #endif

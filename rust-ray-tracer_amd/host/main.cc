@@ -4,7 +4,7 @@
 //
 // Defaults as in the reference: --gltf assets/default.gltf, --output output/render.png, camera and lights
 // from assets/suzanne.gltf (src/gltf.rs:317), MAX_DEPTH 4, t_min 1e-4.  Extensions: --seed, --device,
-// --camera-lights FILE, --extended [--scale S], --stats.
+// --camera-lights FILE, --extended [--scale S], --gpu-build, --stats.
 // All rendering happens on the GPU through the C ABI in include/rrt_ffi.h.
 #include <chrono>
 #include <cstdio>
@@ -31,6 +31,7 @@ void usage() {
                  "        --camera-lights <FILE>     glTF file providing camera and lights (default assets/suzanne.gltf)\n"
                  "        --extended                 extended glTF loader (external .bin, node transforms, u32 indices)\n"
                  "        --scale <FLOAT>            uniform scale for --extended\n"
+                 "        --gpu-build                build large BVHs on the GPU (faster build, slower render)\n"
                  "        --stats                    print a JSON line with rays, samples and kernel time\n\n"
                  "ARGS:\n    <HEIGHT>     Sets the image height\n    <SAMPLES>    Sets the number of samples per pixel\n");
 }
@@ -48,7 +49,7 @@ int main(int argc, char** argv) {
     std::vector<std::string> positional;
     uint32_t seed = 1;
     int device = 0;
-    bool extended = false, stats_json = false;
+    bool extended = false, stats_json = false, gpu_build = false;
     float ext_scale = 1.0f;
 
     for (int i = 1; i < argc; ++i) {
@@ -76,6 +77,7 @@ int main(int argc, char** argv) {
         if (value("camera-lights", nullptr, cam_lights)) continue;
         if (value("scale", nullptr, tmp)) { ext_scale = (float)std::atof(tmp.c_str()); continue; }
         if (a == "--extended") { extended = true; continue; }
+        if (a == "--gpu-build") { gpu_build = true; continue; }
         if (a == "--stats") { stats_json = true; continue; }
         if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) { std::fprintf(stderr, "error: unknown option %s\n", a.c_str()); usage(); return 2; }
         positional.push_back(a);
@@ -111,6 +113,7 @@ int main(int argc, char** argv) {
     cfg.seed = seed;
     cfg.max_depth = 4;   // main.rs:56
     cfg.t_min = 0.0001f; // ray.rs:89
+    cfg.flags = gpu_build ? RRT_CFG_DEVICE_BUILD : 0u;
     rrt_ctx* ctx = nullptr;
     if (rrt_create(&cfg, &ctx) != RRT_OK) return die("device", rrt_last_error(nullptr));
     if (rrt_scene_upload(ctx, scene) != RRT_OK) return die("scene upload", rrt_last_error(ctx));
