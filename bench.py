@@ -196,7 +196,7 @@ def main():
     if rank == 0:
         counting = rrt.Renderer(device=local_rank, seed=args.seed, count_visits=True, device_build=args.device_build)
         counting.upload(scene)
-        probe_spp = min(spp, 8)
+        probe_spp = min(spp, int(os.environ.get("RRT_PROBE_SPP", "8")))  # samples of the counting launch
         counting.render_device(width, height, probe_spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
         cs = counting.render_stats()
         counting.close()
