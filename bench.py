@@ -216,6 +216,9 @@ def main():
                 "lane_util_node": cs.node_visits / max(64 * cs.node_wave_steps, 1),
                 "lane_util_prim": cs.prim_tests / max(64 * cs.prim_wave_steps, 1),
                 "lane_util_shade": cs.rays / max(64 * cs.shade_wave_passes, 1),
+                # where the idle lanes of the node passes are: walk already complete / parked at a leaf since the pass began
+                "node_slots_idle_done": cs.node_slots_lane_done / max(64 * cs.node_wave_steps, 1),
+                "node_slots_idle_at_leaf": cs.node_slots_lane_at_leaf / max(64 * cs.node_wave_steps, 1),
                 "wave_steps_per_ray": {"node": 64 * cs.node_wave_steps / max(cs.rays, 1), "prim": 64 * cs.prim_wave_steps / max(cs.rays, 1),
                                        "shade": 64 * cs.shade_wave_passes / max(cs.rays, 1)}}
         if pmc and "sq_insts_valu" in pmc:

@@ -186,6 +186,11 @@ typedef struct rrt_stats {
     uint64_t prim_wave_steps;
     uint64_t shade_wave_passes;
     uint64_t refill_wave_passes; /* ray batches only: passes in which a wavefront's idle lanes drew new rays  */
+    /* Render kernel: lane slots of node steps that went to lanes whose walk was already complete / to lanes
+     * parked at a leaf when the node pass began (the rest of the idle slots belongs to lanes that reached a
+     * leaf during the pass).  Same units as 64 * node_wave_steps.                                            */
+    uint64_t node_slots_lane_done;
+    uint64_t node_slots_lane_at_leaf;
     float kernel_ms;      /* HIP-event time of the render kernel on its stream                              */
     float reserved;
 } rrt_stats;

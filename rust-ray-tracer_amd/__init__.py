@@ -116,7 +116,8 @@ class HitPOD(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("node_visits", C.c_uint64), ("prim_tests", C.c_uint64),
                 ("node_wave_steps", C.c_uint64), ("prim_wave_steps", C.c_uint64), ("shade_wave_passes", C.c_uint64),
-                ("refill_wave_passes", C.c_uint64),
+                ("refill_wave_passes", C.c_uint64), ("node_slots_lane_done", C.c_uint64),
+                ("node_slots_lane_at_leaf", C.c_uint64),
                 ("kernel_ms", C.c_float), ("reserved", C.c_float)]
 
 

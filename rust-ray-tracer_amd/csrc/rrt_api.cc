@@ -363,7 +363,7 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     if (!c->render_pending) return set_err(c, RRT_ERR_STATE, "rrt_render_stats: no render was issued");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     RRT_HIP(c, hipEventSynchronize(c->ev_stop));
-    unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long h[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8..11] are the work-queue heads
     RRT_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
     float ms = 0.f;
     RRT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
@@ -375,6 +375,8 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     stats->prim_wave_steps = h[4];
     stats->shade_wave_passes = h[5];
     stats->refill_wave_passes = h[6];
+    stats->node_slots_lane_done = h[12];
+    stats->node_slots_lane_at_leaf = h[13];
     stats->samples = c->pending_samples;
     stats->kernel_ms = ms;
     return RRT_OK;

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 5) void k_render(SceneDev 
 
     uint32_t n_rays = 0;
     TraceCounters cnt = {0u, 0u, 0u, 0u, 0u};
+    unsigned long long slots_done = 0ull, slots_leaf = 0ull;  // lane 0, COUNT only
     uint32_t q = blockIdx.x % N_QUEUES;
     uint32_t exhausted = 0;
     // A ticket is always drawn one item ahead, so that the round trip of the atomic overlaps the rendering
@@ -111,8 +112,22 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 5) void k_render(SceneDev 
                 if (n_walk == 0u) break;
                 const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
                 const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
-                if (n_desc == n_walk || n_desc >= share)
-                    trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                if (n_desc == n_walk || n_desc >= share) {
+                    if (COUNT) {
+                        // idle lane slots of this node pass, by what the idle lanes are waiting for
+                        // (the pass is as long as the lane that stayed in it longest)
+                        const uint32_t nodes0 = cnt.nodes;
+                        trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                        uint32_t steps = cnt.nodes - nodes0;
+                        for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
+                        if (lane == 0u) {
+                            slots_done += (unsigned long long)steps * (64u - n_walk);
+                            slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
+                        }
+                    } else {
+                        trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                    }
+                }
                 if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
             }
             // ---- shade phase: every lane with a ray shades its hit and starts its next ray
@@ -166,6 +181,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 5) void k_render(SceneDev 
         if (lane == 0) {
             atomicAdd(&counters[1], nn); atomicAdd(&counters[2], np);
             atomicAdd(&counters[3], wn); atomicAdd(&counters[4], wp); atomicAdd(&counters[5], ws);
+            atomicAdd(&counters[12], slots_done); atomicAdd(&counters[13], slots_leaf);
         }
     }
     if (lane == 0) atomicAdd(&counters[0], rays);
