@@ -22,6 +22,12 @@ static constexpr uint32_t DEFAULT_REFILL_MIN = 16u;
 struct RenderTuning {
     uint32_t node_share_64ths = DEFAULT_NODE_SHARE_64THS;
     uint32_t refill_min = DEFAULT_REFILL_MIN;
+    // Render kernel: a trip's walk phase ends with at most leave_walk lanes still walking if at least leave_ready
+    // lanes wait to shade; the stragglers finish their walk in the next trip.  Measured on MI355X (6 / 16): 10-11 %
+    // faster on the three large scenes, 1 % slower on the 968-triangle one, whose walks are short against a shading
+    // pass -- the library therefore switches it off (leave_walk = 0) for BVHs of fewer than 4096 nodes.
+    uint32_t leave_walk = 6u;
+    uint32_t leave_ready = 16u;
 };
 
 // d_counters: 7 x u64 in device memory {rays, node visits, primitive tests, wave-level node passes, primitive

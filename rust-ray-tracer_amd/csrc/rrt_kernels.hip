@@ -110,6 +110,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 5) void k_render(SceneDev 
             for (;;) {
                 const uint32_t n_walk = (uint32_t)__popcll(__ballot(T.cur != REF_DONE));
                 if (n_walk == 0u) break;
+                // the last few walkers of a trip are left to finish in the next one, once enough lanes wait to shade
+                if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
                 const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
                 const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
                 if (n_desc == n_walk || n_desc >= share) {
@@ -130,8 +132,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 5) void k_render(SceneDev 
                 }
                 if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
             }
-            // ---- shade phase: every lane with a ray shades its hit and starts its next ray
-            if (has_ray) {
+            // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
+            if (has_ray && T.cur == REF_DONE) {
                 n_rays++;
                 if (COUNT && first_active_lane()) cnt.wave_shade++;
                 bool alive;
@@ -394,6 +396,8 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     G.chunk_spp = (spp + n_chunks - 1u) / n_chunks;
     G.n_work = G.n_tiles * G.n_chunks;
     G.node_share_64ths = tuning.node_share_64ths;
+    G.leave_walk = tuning.leave_walk;
+    G.leave_ready = tuning.leave_ready;
     float* out = n_chunks > 1u ? d_partial : d_accum;
     const bool inst = S.has_instances != 0u;
     hipError_t e;
