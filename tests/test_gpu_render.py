@@ -116,6 +116,27 @@ def test_chunked_and_unchunked_renders_agree(rrt, monkeypatch):
     r.close()
 
 
+@pytest.mark.parametrize("name", ["synthetic", "instanced"])
+def test_image_does_not_depend_on_wave_scheduling(rrt, monkeypatch, name):
+    """How a wavefront orders its passes (share of descending lanes that keeps a node pass going, how many stragglers
+    a trip leaves behind, how many lanes must wait before it does) changes the timing only: every pixel follows the same
+    paths and adds its samples in the same order, so the images are identical bit for bit."""
+    r = rrt.Renderer(seed=3)
+    r.upload(helpers.SCENES[name](rrt))
+    monkeypatch.setenv("RRT_CHUNKS", "2")
+    monkeypatch.setenv("RRT_LEAVE_WALK", "0")
+    base, s0 = r.render(96, 54, 12)
+    for knobs in ({"RRT_LEAVE_WALK": "6"}, {"RRT_LEAVE_WALK": "40", "RRT_LEAVE_READY": "1"}, {"RRT_LEAVE_WALK": "63", "RRT_LEAVE_READY": "64"},
+                  {"RRT_LEAVE_WALK": "6", "RRT_NODE_SHARE": "0"}, {"RRT_LEAVE_WALK": "6", "RRT_NODE_SHARE": "64"}):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        img, st = r.render(96, 54, 12)
+        assert st.rays == s0.rays and np.array_equal(img, base), knobs
+        for k in knobs:
+            monkeypatch.delenv(k)
+    r.close()
+
+
 def test_odd_sizes_and_single_sample(rrt, oracle):
     scene = helpers.scene_default(rrt)
     r = rrt.Renderer(seed=2)
