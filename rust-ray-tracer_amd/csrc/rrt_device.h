@@ -475,30 +475,7 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, float x, float 
 // Light list -- reference src/geometry/mod.rs:111-125 over src/geometry/sphere.rs:101-119,217-228
 // and src/geometry/aarect.rs:123-142
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ V3 lights_random(const SceneDev& S, V3 origin, Rng& rng) {
-    const uint32_t pick = rng_index(rng, S.light_count);
-    const LightRec L = S.lights[pick];
-    if (L.type == 0u) {
-        const V3 direction = v3(L.p0, L.p1, L.p2) - origin;
-        const float dist2 = length_squared(direction);
-        const Onb uvw = onb_from_w(direction);
-        const float r1 = rng_f32(rng);
-        const float r2 = rng_f32(rng);
-        const float z = 1.0f + r2 * (sqrtf(1.0f - L.p3 * L.p3 / dist2) - 1.0f);
-        const float phi = 2.0f * RRT_PI * r1;
-        float sn, cs;
-        sincosf(phi, &sn, &cs);
-        const float x = cs * sqrtf(1.0f - z * z);
-        const float y = sn * sqrtf(1.0f - z * z);
-        return onb_local(uvw, v3(x, y, z));
-    } else if (L.type == 1u) {
-        const float rx = rng_range(rng, L.p0, L.p1);
-        const float rz = rng_range(rng, L.p2, L.p3);
-        return v3(rx, L.p4, rz) - origin;
-    }
-    return v3(1.0f, 0.0f, 0.0f);
-}
-
+// (Hittables::random, geometry/mod.rs:118-125, is inlined into `shade`, where it shares code with the cosine lobe.)
 __device__ __forceinline__ float lights_pdf(const SceneDev& S, V3 origin, V3 v) {
     const float weight = 1.0f / (float)S.light_count;
     float sum = 0.0f;
@@ -576,8 +553,48 @@ __device__ __forceinline__ bool shade(const SceneDev& S, const Surface& sf, V3& 
         V3 dir;
         float pdf_val;
         if (S.light_count != 0u) {
-            if (rng_bool_half(rng)) dir = onb_local(uvw, random_cosine_direction(rng));  // pdf.rs:87-94
-            else dir = lights_random(S, sf.p, rng);
+            // MixturePDF::generate, pdf.rs:87-94.  The cosine lobe (pdf.rs:14-26,42) and a sphere light
+            // (sphere.rs:111-119,217-228) both draw r1, r2, form (cos(phi) * radial, sin(phi) * radial, z) and rotate
+            // it into a basis; the lanes of a wavefront that took different branches of the coin flip share that
+            // code, each with its own basis, z and radial (same operations in the same order as the two functions).
+            const bool use_cosine = rng_bool_half(rng);
+            Onb basis = uvw;
+            bool in_basis = true;
+            float sphere_r2_over_d2 = 0.0f;
+            if (!use_cosine) {
+                const uint32_t pick = rng_index(rng, S.light_count);
+                const LightRec L = S.lights[pick];
+                if (L.type == 0u) {
+                    const V3 direction = v3(L.p0, L.p1, L.p2) - sf.p;
+                    sphere_r2_over_d2 = L.p3 * L.p3 / length_squared(direction);
+                    basis = onb_from_w(direction);
+                } else {
+                    in_basis = false;
+                    if (L.type == 1u) {
+                        const float rx = rng_range(rng, L.p0, L.p1);
+                        const float rz = rng_range(rng, L.p2, L.p3);
+                        dir = v3(rx, L.p4, rz) - sf.p;
+                    } else {
+                        dir = v3(1.0f, 0.0f, 0.0f);
+                    }
+                }
+            }
+            if (in_basis) {
+                const float r1 = rng_f32(rng);
+                const float r2 = rng_f32(rng);
+                float z, radial;
+                if (use_cosine) {
+                    z = sqrtf(1.0f - r2);
+                    radial = sqrtf(r2);
+                } else {
+                    z = 1.0f + r2 * (sqrtf(1.0f - sphere_r2_over_d2) - 1.0f);
+                    radial = sqrtf(1.0f - z * z);
+                }
+                const float phi = 2.0f * RRT_PI * r1;
+                float sn, cs;
+                sincosf(phi, &sn, &cs);
+                dir = onb_local(basis, v3(cs * radial, sn * radial, z));
+            }
             const float cosine = dot(normalize(dir), uvw.w);
             const float cos_pdf = fmaxf(cosine / RRT_PI, 0.0f);
             pdf_val = 0.5f * cos_pdf + 0.5f * lights_pdf(S, sf.p, dir);

@@ -217,3 +217,30 @@ def test_full_size_frame_properties(rrt):
     bright = np.argwhere(rgb.sum(-1) >= 3 * 250)
     assert len(bright) and bright[:, 0].mean() < h / 2
     r.close()
+
+
+def test_headline_workload_at_full_size(rrt):
+    """The benchmark's default workload (1,048,576 triangles, 3840x2160) at a few samples per pixel: properties that do
+    not depend on the size -- bitwise reproducibility, sample slices that add up (what the multi-GPU partition relies
+    on), the bounds on rays per sample, and agreement of two independent estimates of the frame."""
+    from rust_ray_tracer_amd import scenes
+
+    scene = scenes.synthetic_mesh(rrt, helpers.ASSETS, subdiv=512)
+    r = rrt.Renderer(seed=1)
+    info = r.upload(scene)
+    assert info.tri_count == 1048576 and info.bvh_depth <= 29
+    w, h = 3840, 2160
+    whole, sw = r.render(w, h, 4, 0)
+    again, sa = r.render(w, h, 4, 0)
+    assert sw.rays == sa.rays and np.array_equal(whole, again)
+    first, s0 = r.render(w, h, 2, 0)
+    second, s1 = r.render(w, h, 2, 2)
+    assert s0.rays + s1.rays == sw.rays
+    assert np.allclose(first + second, whole, rtol=2e-5, atol=1e-5)
+    assert sw.samples == w * h * 4 and sw.samples <= sw.rays <= 4 * sw.samples
+    assert np.all(np.isfinite(whole)) and np.all(whole >= 0)
+    other, so = r.render(w, h, 4, 4)
+    assert abs(int(so.rays) - int(sw.rays)) < 0.005 * sw.rays
+    la, lb = luminance(whole).mean(), luminance(other).mean()
+    assert abs(la - lb) < 0.1 * la
+    r.close()
