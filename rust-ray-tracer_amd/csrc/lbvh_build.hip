@@ -1,4 +1,4 @@
-// lbvh_build.hip -- linear BVH on the GPU: Morton codes -> radix sort -> radix-tree topology (every inner node
+// lbvh_build.hip -- linear BVH on the GPU: 48-bit Morton codes -> radix sort -> radix-tree topology (every inner node
 // from the sorted codes alone, Karras 2012) -> boxes bottom-up, one kernel launch per tree level.
 //
 // The bottom-up pass hands boxes from children to parents only ACROSS kernel launches: a node is finished in
@@ -37,17 +37,19 @@ struct NodeState {
 };
 static_assert(sizeof(NodeState) == 32, "NodeState must be 32 bytes");
 
-__device__ __forceinline__ uint32_t expand10(uint32_t v) {
-    v &= 0x3FFu;
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    v = (v | (v << 2)) & 0x09249249u;
-    return v;
+// Spreads the low 16 bits of v to every third bit of a 64-bit word.
+__device__ __forceinline__ unsigned long long spread3(uint32_t v) {
+    unsigned long long x = v & 0xFFFFu;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
 }
 
-// 30-bit Morton code of the box centre on the BVH's grid (the top 10 of the grid's 16 bits per axis).
-__global__ void k_morton(const BuildPrim* __restrict__ prims, uint32_t n, Grid g, uint32_t* __restrict__ keys,
+// 48-bit Morton code of the box centre: the three 16-bit plane indices of the BVH's grid, interleaved.
+__global__ void k_morton(const BuildPrim* __restrict__ prims, uint32_t n, Grid g, unsigned long long* __restrict__ keys,
                          uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -56,9 +58,9 @@ __global__ void k_morton(const BuildPrim* __restrict__ prims, uint32_t n, Grid g
     for (int a = 0; a < 3; ++a) {
         const float c = 0.5f * (p.bmin[a] + p.bmax[a]);
         const float f = fminf(fmaxf((c - g.origin[a]) / g.step[a], 0.0f), 65535.0f);
-        q[a] = (uint32_t)f >> 6;
+        q[a] = (uint32_t)f;
     }
-    keys[i] = expand10(q[0]) | (expand10(q[1]) << 1) | (expand10(q[2]) << 2);
+    keys[i] = spread3(q[0]) | (spread3(q[1]) << 1) | (spread3(q[2]) << 2);
     vals[i] = i;
 }
 
@@ -80,15 +82,15 @@ __global__ void k_gather(const BuildPrim* __restrict__ prims, const uint32_t* __
 }
 
 // Length of the common prefix of the keys at sorted positions i and j; the position breaks ties between equal
-// Morton codes, so all keys are distinct.  -1 outside the array.
-__device__ __forceinline__ int common_prefix(const uint32_t* __restrict__ keys, int n, int i, int j) {
+// Morton codes (as 32 further bits), so all keys are distinct.  -1 outside the array.
+__device__ __forceinline__ int common_prefix(const unsigned long long* __restrict__ keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    const unsigned long long a = ((unsigned long long)keys[i] << 32) | (unsigned)i;
-    const unsigned long long b = ((unsigned long long)keys[j] << 32) | (unsigned)j;
-    return __clzll((long long)(a ^ b));
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((int)((unsigned)i ^ (unsigned)j));
 }
 
-__global__ void k_topology(const uint32_t* __restrict__ keys, int n, Topo* __restrict__ topo) {
+__global__ void k_topology(const unsigned long long* __restrict__ keys, int n, Topo* __restrict__ topo) {
     const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
     if (i >= n - 1) return;
     const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
@@ -224,7 +226,8 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QN
     if (n < 2u || n > REF_OFFSET_MASK) return hipErrorInvalidValue;
     Buffers B;
     BuildPrim* d_prims;
-    uint32_t *keys_a, *keys_b, *vals_a, *vals_b, *is_tri, *tri_prefix;
+    unsigned long long *keys_a, *keys_b;
+    uint32_t *vals_a, *vals_b, *is_tri, *tri_prefix;
     LeafInfo* leaf;
     Topo* topo;
     NodeState* st;
@@ -241,7 +244,7 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QN
     LBVH_TRY(B.alloc(&st, n));
     LBVH_TRY(B.alloc(&tri_tmp, tri_count));
     size_t sort_bytes = 0, scan_bytes = 0;
-    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 30, (hipStream_t)0));
+    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 48, (hipStream_t)0));
     LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_tri, tri_prefix, (int)(n + 1u), (hipStream_t)0));
     unsigned char* temp;
     LBVH_TRY(B.alloc(&temp, sort_bytes > scan_bytes ? sort_bytes : scan_bytes));
@@ -253,7 +256,7 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QN
     const unsigned blocks = (n + BLOCK - 1u) / BLOCK, blocks1 = (n + 1u + BLOCK - 1u) / BLOCK;
     LBVH_TRY(hipEventRecord(B.e0, s));
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BLOCK), 0, s, d_prims, n, grid, keys_a, vals_a);
-    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(temp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 30, s));
+    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(temp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 48, s));
     hipLaunchKernelGGL(k_gather, dim3(blocks1), dim3(BLOCK), 0, s, d_prims, vals_b, n, leaf, is_tri);
     LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, is_tri, tri_prefix, (int)(n + 1u), s));
     hipLaunchKernelGGL(k_topology, dim3(blocks), dim3(BLOCK), 0, s, keys_b, (int)n, topo);

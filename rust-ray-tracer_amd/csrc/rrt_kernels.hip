@@ -33,7 +33,7 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 }
 
 template <bool INST, bool COUNT>
-__global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 5) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+__global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
     __shared__ int s_stack[STACK_DEPTH * RENDER_BLOCK];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* _
 // wavefront are idle, they take the next indices of the wavefront's block.  counters (COUNT only): {-, node visits, primitive tests, node passes, primitive
 // passes, -, refill passes}.
 template <bool INST, bool COUNT>
-__global__ __launch_bounds__(RENDER_BLOCK, 5) void k_trace_stream(SceneDev S, const rrt_ray* __restrict__ rays, uint32_t n,
+__global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, const rrt_ray* __restrict__ rays, uint32_t n,
                                                                   float tmin, float tmax, rrt_hit* __restrict__ out,
                                                                   unsigned int* __restrict__ head, uint32_t refill_min,
                                                                   uint32_t node_share_64ths,

@@ -164,9 +164,11 @@ struct RenderGeom {
 
 // Per-lane traversal stack entries (LDS).  One inner-node step pushes at most one entry, so the stack never
 // holds more than (tree depth) entries plus the bottom marker and, for instanced scenes, one exit marker;
-// the builder bounds the combined depth of top level + bottom level to MAX_TREE_DEPTH.
-static constexpr int STACK_DEPTH = 32;
-static constexpr uint32_t MAX_TREE_DEPTH = 29;
+// the builder bounds the combined depth of top level + bottom level to MAX_TREE_DEPTH.  40 entries x 256 lanes x
+// 4 bytes = 40 KB per workgroup: four workgroups fill the 160 KB of LDS of a CU, and four are as fast as five
+// (measured); the depth leaves room for the linear BVHs of the GPU builder (31 levels for ten million triangles).
+static constexpr int STACK_DEPTH = 40;
+static constexpr uint32_t MAX_TREE_DEPTH = 37;
 
 }  // namespace rrt
 #endif

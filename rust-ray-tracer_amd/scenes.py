@@ -6,6 +6,7 @@
                               bufferView per accessor, every serde-required field present, camera + point light).
 * ``synthetic_mesh``       -- fixed-seed displaced height field, 2 * nx * nz triangles (default 1,048,576).
 * ``synthetic_instanced``  -- one mesh instanced on a jittered grid as ``Translate(RotateY(mesh))``.
+* ``synthetic_flattened``  -- the same scene with every instance written out: ten million unique triangles.
 * ``metal_rough_spheres``  -- ``assets/MetalRoughSpheres`` through the extended loader.
 
 All generators are deterministic (integer hashing, no global RNG state).
@@ -252,6 +253,37 @@ def synthetic_instanced(rrt, assets_dir: str, n_lat: int = 250, n_lon: int = 251
     s.add_sphere_light(lp, 0.6)
     s.camera = rrt.Camera(16.0 / 9.0, 40.0, look_at_c2w((0.0, 9.0, ext * 0.75), (0.0, 0.0, 0.0)))
     s.background = (0.051, 0.051, 0.051)
+    return s
+
+
+def synthetic_flattened(rrt, assets_dir: str, n_lat: int = 250, n_lon: int = 251, grid: int = 10, seed: int = 99):
+    """The scene of `synthetic_instanced` with every instance written out as triangles of its own: grid*grid copies of
+    the ~100k-triangle blob, rotated about y and translated on the host (transform.rs:101-124 gives the point map
+    x' = cos*x + sin*z, z' = -sin*x + cos*z), about ten million unique triangles in one flat BVH."""
+    src = synthetic_instanced(rrt, assets_dir, n_lat, n_lon, grid, seed)
+    s = rrt.Scene()
+    grey = s.add_material(rrt.Lambertian(0.7, 0.7, 0.7))
+    metal = s.add_material(rrt.Metal((0.8, 0.6, 0.3), 0.2))
+    ground = s.add_material(rrt.Lambertian(0.45, 0.5, 0.45))
+    light_m = s.add_material(rrt.DiffuseLight(4000.0, 4000.0, 4000.0))
+    tris = blob_mesh(n_lat, n_lon, 1.0, 0.5, seed).astype(np.float32)
+    half = len(tris) // 2
+    ext = grid * 3.0
+    g = np.array([[[-ext, -1.3, -ext], [-ext, -1.3, ext], [ext, -1.3, -ext]],
+                  [[ext, -1.3, -ext], [-ext, -1.3, ext], [ext, -1.3, ext]]], np.float32)
+    s.add_triangles(g, ground)
+    for _, sn, cs, off in src.instances:
+        v = np.empty_like(tris)
+        v[..., 0] = np.float32(cs) * tris[..., 0] + np.float32(sn) * tris[..., 2] + np.float32(off[0])
+        v[..., 1] = tris[..., 1] + np.float32(off[1])
+        v[..., 2] = -np.float32(sn) * tris[..., 0] + np.float32(cs) * tris[..., 2] + np.float32(off[2])
+        s.add_triangles(v[:half], grey)
+        s.add_triangles(v[half:], metal)
+    lp = (0.0, 14.0, 0.0)
+    s.add_sphere(lp, 0.6, light_m)
+    s.add_sphere_light(lp, 0.6)
+    s.camera = src.camera
+    s.background = src.background
     return s
 
 

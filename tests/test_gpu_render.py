@@ -228,7 +228,7 @@ def test_headline_workload_at_full_size(rrt):
     scene = scenes.synthetic_mesh(rrt, helpers.ASSETS, subdiv=512)
     r = rrt.Renderer(seed=1)
     info = r.upload(scene)
-    assert info.tri_count == 1048576 and info.bvh_depth <= 29
+    assert info.tri_count == 1048576 and info.bvh_depth <= 37
     w, h = 3840, 2160
     whole, sw = r.render(w, h, 4, 0)
     again, sa = r.render(w, h, 4, 0)

@@ -15,7 +15,7 @@ def test_scene_check_counts_match_the_oracle_flattening(rrt, oracle, name):
     info = s.check()
     o = oracle.OracleScene(s)
     assert info.prim_count == o.prim_count
-    assert info.bvh_depth <= 29  # the traversal stack holds 32 entries
+    assert info.bvh_depth <= 37  # the traversal stack holds 40 entries
     assert info.node_count >= 1 and info.device_bytes > 0
 
 
@@ -40,7 +40,7 @@ def test_degenerate_scenes_build(rrt):
     tri = np.array([[(0, 0, 0), (1, 0, 0), (0, 1, 0)]], np.float32)
     t.add_triangles(np.repeat(tri, 1000, axis=0), 0)  # 1000 coincident triangles: no spatial split exists
     info = t.check()
-    assert info.prim_count == 1000 and info.bvh_depth <= 29
+    assert info.prim_count == 1000 and info.bvh_depth <= 37
 
 
 def test_invalid_scenes_are_rejected_with_a_message(rrt):
@@ -79,7 +79,7 @@ def test_large_mesh_build_is_bounded_and_fast(rrt):
     s.add_triangles(scenes.grid_triangles(scenes.height_field(256, 256, 0.1, 3.0, seed=2)), m)
     info = s.check()
     assert info.prim_count == 2 * 256 * 256 and info.tri_count == info.prim_count
-    assert info.bvh_depth <= 29
+    assert info.bvh_depth <= 37
     assert info.node_count < info.prim_count  # several triangles per leaf
     # 32-byte nodes + 48-byte triangle records + one record each of the (empty) other arrays and the material
     assert info.device_bytes == info.node_count * 32 + info.tri_count * 48 + 32 + 32 + 64 + 32 + 32
