@@ -225,6 +225,9 @@ def main():
                 "node_slots_idle_at_leaf": cs.node_slots_lane_at_leaf / max(64 * cs.node_wave_steps, 1),
                 "wave_steps_per_ray": {"node": 64 * cs.node_wave_steps / max(cs.rays, 1), "prim": 64 * cs.prim_wave_steps / max(cs.rays, 1),
                                        "shade": 64 * cs.shade_wave_passes / max(cs.rays, 1)}}
+        roof["note"] = ("achieved = algorithmic bytes (nodes and primitive records the rays touch) / kernel time; the caches serve "
+                        "most of them, the HBM-side bytes per launch are `traffic`; the kernel is bound by vector-ALU issue and "
+                        "SIMD divergence (`valu`, `lane_util_*`)")
         if pmc and "sq_insts_valu" in pmc:
             per_simd = pmc["sq_insts_valu"] / pmc["simds"]
             # the kernel is bound by vector-ALU issue, not by HBM: share of the launch a SIMD spends issuing VALU

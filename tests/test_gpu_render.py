@@ -195,7 +195,7 @@ def test_tonemap_matches_the_reference_formula(rrt, oracle):
 
 
 def test_full_size_frame_properties(rrt):
-    """BASELINE config 2 at its full 1920x1080 size (few samples): size-independent properties."""
+    """Benchmark configuration 2 (suzanne) at its full 1920x1080 size (few samples): size-independent properties."""
     scene = helpers.scene_suzanne(rrt)
     r = rrt.Renderer(seed=1)
     r.upload(scene)
