@@ -258,6 +258,7 @@ def main():
         print(json.dumps(out), flush=True)
     renderer.close()
     if world > 1:
+        dist.barrier()  # rank 0 is still measuring its roofline figures: nobody tears the group down before it is done
         dist.destroy_process_group()
 
 

@@ -200,7 +200,11 @@ def synthetic_mesh(rrt, assets_dir: str, subdiv: int = 512, seed: int = 1234):
     """The 2 * (2*subdiv) * subdiv triangle scene, loaded back through the glTF front end in compat mode."""
     path = os.path.join(_cache_dir(), f"synthetic_{subdiv}_{seed}.gltf")
     if not os.path.exists(path):
-        synthetic_mesh_gltf(path, nx=2 * subdiv, nz=subdiv, cell=0.05 * 512 / subdiv, seed=seed)
+        # several ranks of one job may get here at the same time: each writes a file of its own and moves it into
+        # place in one step, so that nobody ever reads a half-written scene
+        tmp = f"{path}.{os.getpid()}.tmp"
+        synthetic_mesh_gltf(tmp, nx=2 * subdiv, nz=subdiv, cell=0.05 * 512 / subdiv, seed=seed)
+        os.replace(tmp, path)
     return rrt.Scene.from_gltf_file(path, path)
 
 
