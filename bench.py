@@ -139,11 +139,35 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # Rehearsal on a box with fewer GPUs than ranks (RRT_BENCH_REHEARSAL=1): ranks share the GPUs there are and the
+    # reduce goes through host memory with gloo, because RCCL refuses two ranks on one GPU.  Not a measurement.
+    rehearsal = os.environ.get("RRT_BENCH_REHEARSAL") == "1"
+    gpu_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(gpu_index)
+    device = torch.device("cuda", gpu_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    def reduce_to_root(t):
+        if rehearsal:
+            h = t.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                t.copy_(h)
+        else:
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+
+    def all_reduce(t, op):
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
     rrt = rrt_pkg.load()
     scene, width, height, spp, workload = build_scene(rrt, args.config)
@@ -152,7 +176,7 @@ def main():
     spp_total = spp * world
     spp_offset = rank * spp
 
-    renderer = rrt.Renderer(device=local_rank, seed=args.seed, device_build=args.device_build)
+    renderer = rrt.Renderer(device=gpu_index, seed=args.seed, device_build=args.device_build)
     info = renderer.upload(scene)
     accum = torch.empty((height, width, 3), dtype=torch.float32, device=device)
     rgb8 = torch.empty((height, width, 3), dtype=torch.uint8, device=device)
@@ -166,7 +190,7 @@ def main():
         renderer.render_device(width, height, spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
         st = renderer.render_stats()  # waits for the kernel; its HIP events are on `stream`
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            reduce_to_root(accum)
         if rank == 0:
             renderer.tonemap_device(accum.data_ptr(), width, height, spp_total, rgb8.data_ptr(), stream.cuda_stream)
         if record:
@@ -189,8 +213,8 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     r = torch.tensor([float(rays_per_step)], dtype=torch.float64, device=device)
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        all_reduce(t, dist.ReduceOp.MAX)
+        all_reduce(r, dist.ReduceOp.SUM)
     elapsed = float(t.item())
     rays_all = float(r.item())  # rays of one step, all ranks
 
@@ -198,7 +222,7 @@ def main():
     roof = None
     cpu = None
     if rank == 0:
-        counting = rrt.Renderer(device=local_rank, seed=args.seed, count_visits=True, device_build=args.device_build)
+        counting = rrt.Renderer(device=gpu_index, seed=args.seed, count_visits=True, device_build=args.device_build)
         counting.upload(scene)
         probe_spp = min(spp, int(os.environ.get("RRT_PROBE_SPP", "8")))  # samples of the counting launch
         counting.render_device(width, height, probe_spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
@@ -245,7 +269,7 @@ def main():
         out = {
             "metric": "Mrays/s (whole node)", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.config >= 4 else "reference asset (bundled glTF), random-free scene; counter-RNG seed %d" % args.seed,
+            "vs_baseline": None, "dtype": "f32", "data": ("REHEARSAL, ranks share GPUs, not a measurement; " if rehearsal else "") + "synthetic" if args.config >= 4 else "reference asset (bundled glTF), random-free scene; counter-RNG seed %d" % args.seed,
             "config": {"workload": workload, "width": width, "height": height, "spp_per_gpu": spp, "spp_total": spp_total,
                        "max_depth": 4, "prims": info.prim_count, "bvh_nodes": info.node_count, "bvh_depth": info.bvh_depth,
                        "scene_bytes": info.device_bytes, "bvh_build_ms": info.build_ms,
