@@ -194,3 +194,45 @@ def test_streaming_batch_sizes_order_and_counters(rrt, oracle, renderer_cache, m
     assert st.node_visits >= st.rays and st.node_wave_steps * 64 >= st.node_visits
     assert st.prim_wave_steps * 64 >= st.prim_tests > 0 and st.refill_wave_passes > 0
     rc.close()
+
+
+@pytest.mark.parametrize("device_build", [False, True])
+def test_random_soups_with_hostile_coordinates(rrt, oracle, monkeypatch, device_build):
+    """The box test is the only inexact step of the walk (child boxes live on a 16-bit grid, plane distances come from
+    one fma with a hardware reciprocal); it must never cull a hit the exhaustive search finds.  Triangle soups far from
+    the origin, tiny or huge, flat in one axis, with rays along the axes, from inside and from far outside."""
+    monkeypatch.setenv("RRT_DEVICE_BUILD_MIN", "2")
+    g = np.random.default_rng(2024)
+    cases = [(1.0, 0.0, None), (1e-3, 0.0, None), (1e4, 0.0, None), (1.0, 1e4, None), (1e-2, 3e3, None), (50.0, -2e5, None),
+             (1.0, 0.0, 0), (1.0, 0.0, 1), (10.0, 500.0, 2), (1.0, 7.0, None)]
+    for scale, offset, flat_axis in cases:
+        n = 1500
+        centres = g.uniform(-1, 1, (n, 1, 3)) * scale
+        tris = centres + g.normal(0, 0.03 * scale, (n, 3, 3))
+        if flat_axis is not None:
+            tris[..., flat_axis] = 0.25 * scale  # every triangle in one plane: boxes of zero thickness
+            tris[n // 2:, 1, :], tris[n // 2:, 2, :] = tris[n // 2:, 2, :].copy(), tris[n // 2:, 1, :].copy()  # both facings
+        tris = (tris + offset).astype(np.float32)
+        s = rrt.Scene()
+        m = s.add_material(rrt.Lambertian(0.5, 0.5, 0.5))
+        s.add_triangles(tris, m)
+        s.add_sphere((offset + 0.3 * scale, offset, offset - 0.2 * scale), 0.2 * scale, m)
+        s.camera = rrt.Camera(1.0, 40.0, np.float32([[1, 0, 0, offset], [0, 1, 0, offset], [0, 0, 1, offset + 4 * scale]]))
+        r = rrt.Renderer(device_build=device_build)
+        r.upload(s)
+        k = 1024
+        inside = g.uniform(-1, 1, (k, 3)) * scale + offset
+        outside = g.normal(0, 1, (k, 3))
+        outside = outside / np.linalg.norm(outside, axis=1, keepdims=True) * 30 * scale + offset
+        target = g.uniform(-1, 1, (2 * k, 3)) * scale + offset
+        origins = np.concatenate([inside, outside])
+        dirs = target - origins
+        dirs[:k] = g.normal(0, 1, (k, 3))
+        axis = np.zeros((384, 3))
+        axis[np.arange(384), g.integers(0, 3, 384)] = g.choice([-1.0, 1.0], 384)
+        axis_o = tris[g.integers(0, n, 384)].mean(1) - axis * 3 * scale + g.normal(0, 0.01 * scale, (384, 3))  # along an axis, through a triangle
+        rays = helpers.make_rays(np.concatenate([origins, axis_o]).astype(np.float32), np.concatenate([dirs, axis]).astype(np.float32))
+        got, want = r.intersect(rays, t_min=1e-4 * scale), oracle.OracleScene(s).intersect(rays, t_min=1e-4 * scale)
+        assert (want["prim_id"] >= 0).mean() > 0.02, (scale, offset, flat_axis)  # (tiny triangles fail the reference's det > 1e-5)
+        helpers.assert_hits_match(got, want)
+        r.close()
