@@ -216,7 +216,8 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     S.light_count = (uint32_t)hs.lights.size();
     S.root = hs.root;
     S.has_instances = hs.has_instances ? 1u : 0u;
-    S.pad = 0;
+    S.light_weight = S.light_count ? 1.0f / (float)S.light_count : 0.0f;
+    S.light_zone = S.light_count ? (uint32_t)((0x100000000ull) % S.light_count) : 0u;
     S.cam = hs.cam;
     for (int a = 0; a < 3; ++a) S.background[a] = hs.background[a];
     S.t_min = c->cfg.t_min;

@@ -76,9 +76,9 @@ __device__ __forceinline__ float rng_range(Rng& r, float lo, float hi) {
 }
 // rand 0.8 `gen_bool(0.5)`: a u64 draw compared with 2^63, i.e. one fair bit
 __device__ __forceinline__ bool rng_bool_half(Rng& r) { return (rng_u32(r) >> 31) == 0u; }
-// rand 0.8 `gen_range(0..n)`: unbiased integer in [0, n) (widening multiply with rejection)
-__device__ __forceinline__ uint32_t rng_index(Rng& r, uint32_t n) {
-    const uint32_t zone = (uint32_t)(-(int32_t)n) % n;  // 2^32 mod n
+// rand 0.8 `gen_range(0..n)`: unbiased integer in [0, n) (widening multiply with rejection); zone = 2^32 mod n is
+// computed once on the host (an integer division per call would cost more than the draw)
+__device__ __forceinline__ uint32_t rng_index(Rng& r, uint32_t n, uint32_t zone) {
     for (;;) {
         uint64_t m = (uint64_t)rng_u32(r) * (uint64_t)n;
         if ((uint32_t)m >= zone) return (uint32_t)(m >> 32);
@@ -477,7 +477,7 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, float x, float 
 // ---------------------------------------------------------------------------------------------
 // (Hittables::random, geometry/mod.rs:118-125, is inlined into `shade`, where it shares code with the cosine lobe.)
 __device__ __forceinline__ float lights_pdf(const SceneDev& S, V3 origin, V3 v) {
-    const float weight = 1.0f / (float)S.light_count;
+    const float weight = S.light_weight;  // 1 / light count, geometry/mod.rs:112
     float sum = 0.0f;
     for (uint32_t i = 0; i < S.light_count; ++i) {
         const LightRec L = S.lights[i];
@@ -562,7 +562,7 @@ __device__ __forceinline__ bool shade(const SceneDev& S, const Surface& sf, V3& 
             bool in_basis = true;
             float sphere_r2_over_d2 = 0.0f;
             if (!use_cosine) {
-                const uint32_t pick = rng_index(rng, S.light_count);
+                const uint32_t pick = rng_index(rng, S.light_count, S.light_zone);
                 const LightRec L = S.lights[pick];
                 if (L.type == 0u) {
                     const V3 direction = v3(L.p0, L.p1, L.p2) - sf.p;

@@ -141,12 +141,13 @@ struct SceneDev {
     uint32_t light_count;
     int32_t root;       // root node of the top-level BVH
     uint32_t has_instances;
-    uint32_t pad;
+    uint32_t light_zone;  // 2^32 mod light_count (rejection zone of the uniform light pick)
     CameraRec cam;
     float background[3];
     float t_min;
     uint32_t max_depth;
     uint32_t seed;
+    float light_weight;  // 1.0f / light_count
     Grid grid;          // grid of the top-level BVH (world space)
 };
 
