@@ -244,3 +244,28 @@ def test_headline_workload_at_full_size(rrt):
     la, lb = luminance(whole).mean(), luminance(other).mean()
     assert abs(la - lb) < 0.1 * la
     r.close()
+
+
+def test_metal_rough_spheres_asset_matches_the_oracle(rrt, oracle):
+    """Benchmark configuration 3: assets/MetalRoughSpheres through the extended loader (external .bin, node
+    translations, 1,038,800 triangles, Lambertian and Metal by the metallic factor).  Closest hits against the
+    exhaustive search on a ray subset and a small same-seed image."""
+    from rust_ray_tracer_amd import scenes
+
+    scene = scenes.metal_rough_spheres(rrt, helpers.ASSETS)
+    assert scene.triangle_count == 1038800
+    r = rrt.Renderer(seed=4)
+    r.upload(scene)
+    o = oracle.OracleScene(scene)
+    prim = helpers.primary_rays(o, 2560, 1440, 768, seed=21)
+    bounce = helpers.bounce_rays(o, prim[:256], seed=22)
+    rays = np.concatenate([prim, bounce])
+    want = o.intersect(rays)
+    assert (want["prim_id"] >= 0).mean() > 0.2
+    helpers.assert_hits_match(r.intersect(rays), want)
+    w, h, spp = 40, 22, 2
+    accum, st = r.render(w, h, spp)
+    ref, ref_rays = o.render(w, h, spp, seed=4)
+    assert abs(int(st.rays) - ref_rays) <= 2
+    assert rel_l1(accum, ref) <= 2e-3
+    r.close()
