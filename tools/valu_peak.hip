@@ -72,6 +72,70 @@ __global__ __launch_bounds__(256) void k_valu(float* out, int trips, float a, fl
     out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
 }
 
+// One instruction form repeated on 8 registers (dependent distance 8).
+#define ONE_OP_KERNEL(NAME, ASM)                                                                                      \
+    __global__ __launch_bounds__(256) void NAME(float* out, int trips, float a, float b) {                            \
+        float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7; \
+        for (int i = 0; i < trips; ++i) {                                                                             \
+            REP8(asm volatile(ASM(%0) ASM(%1) ASM(%2) ASM(%3) ASM(%4) ASM(%5) ASM(%6) ASM(%7)                          \
+                              : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)        \
+                              : "v"(a), "v"(b));)                                                                     \
+        }                                                                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;                           \
+    }
+#define A_CVT(r) "v_cvt_f32_u32 " #r ", " #r "\n"
+#define A_CVTB(r) "v_cvt_f32_ubyte1 " #r ", " #r "\n"
+#define A_ALIGN(r) "v_alignbit_b32 " #r ", " #r ", " #r ", %8\n"
+#define A_AND(r) "v_and_b32 " #r ", %8, " #r "\n"
+#define A_LSHR(r) "v_lshrrev_b32 " #r ", 16, " #r "\n"
+#define A_MIN(r) "v_min_f32 " #r ", " #r ", %8\n"
+#define A_MAX3(r) "v_max3_f32 " #r ", " #r ", %8, %9\n"
+#define A_MUL(r) "v_mul_f32 " #r ", " #r ", %8\n"
+#define A_ADD(r) "v_add_f32 " #r ", " #r ", %8\n"
+#define A_ADDU(r) "v_add_u32 " #r ", " #r ", %8\n"
+#define A_PERM(r) "v_perm_b32 " #r ", " #r ", %8, %9\n"
+#define A_BFE(r) "v_bfe_u32 " #r ", " #r ", 4, 16\n"
+#define A_XOR(r) "v_xor_b32 " #r ", %8, " #r "\n"
+#define A_MULLO(r) "v_mul_lo_u32 " #r ", " #r ", %8\n"
+#define A_MOV(r) "v_mov_b32 " #r ", %8\n"
+#define A_LSHLOR(r) "v_lshl_or_b32 " #r ", " #r ", 16, %8\n"
+ONE_OP_KERNEL(k_cvt, A_CVT)
+ONE_OP_KERNEL(k_cvtb, A_CVTB)
+ONE_OP_KERNEL(k_align, A_ALIGN)
+ONE_OP_KERNEL(k_and, A_AND)
+ONE_OP_KERNEL(k_lshr, A_LSHR)
+ONE_OP_KERNEL(k_min, A_MIN)
+ONE_OP_KERNEL(k_max3, A_MAX3)
+ONE_OP_KERNEL(k_mul, A_MUL)
+ONE_OP_KERNEL(k_add, A_ADD)
+ONE_OP_KERNEL(k_addu, A_ADDU)
+ONE_OP_KERNEL(k_perm, A_PERM)
+ONE_OP_KERNEL(k_bfe, A_BFE)
+ONE_OP_KERNEL(k_xor, A_XOR)
+ONE_OP_KERNEL(k_mullo, A_MULLO)
+ONE_OP_KERNEL(k_mov, A_MOV)
+ONE_OP_KERNEL(k_lshlor, A_LSHLOR)
+
+typedef void (*one_op_kernel)(float*, int, float, float);
+static void run_one(const char* name, one_op_kernel k, float* d_out, int cus, double ghz) {
+    const int trips = 4096, wps = 4;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k, dim3(cus * wps), dim3(256), 0, 0, d_out, 64, 1.0001f, 0.5f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k, dim3(cus * wps), dim3(256), 0, 0, d_out, trips, 1.0001f, 0.5f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-28s waves/SIMD %d  %.3f ms  %.2f cycles per wave-instruction per SIMD (at %.2f GHz)\n", name, wps, ms,
+           ms * 1e-3 * ghz * 1e9 / ((double)trips * 64.0 * wps), ghz);
+    CHECK(hipEventDestroy(e0));
+    CHECK(hipEventDestroy(e1));
+}
+
 template <int MODE>
 static void run(const char* name, float* d_out, int cus, double ghz) {
     const int trips = 4096;
@@ -111,6 +175,23 @@ int main() {
     run<4>("v_fma_f32 dependent chain", d_out, p.multiProcessorCount, ghz);
     run<5>("v_cmp + v_cndmask", d_out, p.multiProcessorCount, ghz);
     run<6>("v_pk_fma_f32", d_out, p.multiProcessorCount, ghz);
+    const int cus = p.multiProcessorCount;
+    run_one("v_cvt_f32_u32", k_cvt, d_out, cus, ghz);
+    run_one("v_cvt_f32_ubyte1", k_cvtb, d_out, cus, ghz);
+    run_one("v_alignbit_b32", k_align, d_out, cus, ghz);
+    run_one("v_and_b32", k_and, d_out, cus, ghz);
+    run_one("v_lshrrev_b32", k_lshr, d_out, cus, ghz);
+    run_one("v_min_f32", k_min, d_out, cus, ghz);
+    run_one("v_max3_f32", k_max3, d_out, cus, ghz);
+    run_one("v_mul_f32", k_mul, d_out, cus, ghz);
+    run_one("v_add_f32", k_add, d_out, cus, ghz);
+    run_one("v_add_u32", k_addu, d_out, cus, ghz);
+    run_one("v_perm_b32", k_perm, d_out, cus, ghz);
+    run_one("v_bfe_u32", k_bfe, d_out, cus, ghz);
+    run_one("v_xor_b32", k_xor, d_out, cus, ghz);
+    run_one("v_mul_lo_u32", k_mullo, d_out, cus, ghz);
+    run_one("v_mov_b32", k_mov, d_out, cus, ghz);
+    run_one("v_lshl_or_b32", k_lshlor, d_out, cus, ghz);
     CHECK(hipFree(d_out));
     return 0;
 }
