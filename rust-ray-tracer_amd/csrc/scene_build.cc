@@ -4,15 +4,34 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 #include "bvh_builder.h"
 
 namespace rrt {
 namespace {
 
+// Runs body(lo, hi) over [0, n) in contiguous pieces, on up to `threads` host threads when n is large.
+template <typename F>
+static void parallel_for(uint32_t n, unsigned threads, F body) {
+    const unsigned pieces = n >= (1u << 16) ? std::min<unsigned>(std::max(threads, 1u), 64u) : 1u;
+    if (pieces <= 1u) {
+        body(0u, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned k = 0; k < pieces; ++k) {
+        const uint32_t lo = (uint32_t)((uint64_t)n * k / pieces), hi = (uint32_t)((uint64_t)n * (k + 1) / pieces);
+        pool.emplace_back([=, &body]() { body(lo, hi); });
+    }
+    for (std::thread& t : pool) t.join();
+}
+
 struct Expander {
     const rrt_scene_desc* d;
+    unsigned threads = 1;
     HostScene* hs;
     std::vector<TriRec> tri_src;  // triangle records in submission order; reordered into leaf order at the end
     float pad = 0.f;              // conservative extra padding of every box
@@ -72,26 +91,36 @@ struct Expander {
             switch (ob.type) {
                 case RRT_OBJ_TRIANGLES: {
                     if ((uint64_t)ob.first + ob.count > d->triangle_count) return fail("triangle run out of range");
-                    for (uint32_t i = 0; i < ob.count; ++i) {
-                        const rrt_triangle& t = d->triangles[ob.first + i];
-                        if (t.material >= d->material_count) return fail("triangle material index out of range");
-                        TriRec rec;
-                        for (int a = 0; a < 3; ++a) {
-                            rec.v0[a] = t.v0[a];
-                            rec.e1[a] = t.v1[a] - t.v0[a];  // triangle.rs:28-29
-                            rec.e2[a] = t.v2[a] - t.v0[a];
+                    // large runs are filled by several threads: every triangle has its slot and its id up front
+                    const size_t src0 = tri_src.size(), prim0 = prims.size();
+                    const uint32_t id0 = id;
+                    tri_src.resize(src0 + ob.count);
+                    prims.resize(prim0 + ob.count);
+                    std::atomic<bool> bad_material{false};
+                    parallel_for(ob.count, threads, [&](uint32_t lo, uint32_t hi) {
+                        for (uint32_t i = lo; i < hi; ++i) {
+                            const rrt_triangle& t = d->triangles[ob.first + i];
+                            if (t.material >= d->material_count) bad_material.store(true, std::memory_order_relaxed);
+                            TriRec rec;
+                            for (int a = 0; a < 3; ++a) {
+                                rec.v0[a] = t.v0[a];
+                                rec.e1[a] = t.v1[a] - t.v0[a];  // triangle.rs:28-29
+                                rec.e2[a] = t.v2[a] - t.v0[a];
+                            }
+                            rec.id = id0 + i;
+                            rec.material = t.material;
+                            rec.pad = 0;
+                            BuildPrim p;
+                            tri_box(t, p.bmin, p.bmax);
+                            p.kind = KIND_TRI;
+                            p.index = (uint32_t)(src0 + i);
+                            widen(p);
+                            tri_src[src0 + i] = rec;
+                            prims[prim0 + i] = p;
                         }
-                        rec.id = id++;
-                        rec.material = t.material;
-                        rec.pad = 0;
-                        BuildPrim p;
-                        tri_box(t, p.bmin, p.bmax);
-                        p.kind = KIND_TRI;
-                        p.index = (uint32_t)tri_src.size();
-                        widen(p);
-                        tri_src.push_back(rec);
-                        prims.push_back(p);
-                    }
+                    });
+                    if (bad_material.load()) return fail("triangle material index out of range");
+                    id += ob.count;
                     break;
                 }
                 case RRT_OBJ_SPHERES: {
@@ -300,6 +329,7 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
 
     Expander ex;
     ex.d = d;
+    ex.threads = threads;
     ex.hs = &hs;
     ex.err = &err;
     ex.pad = scale * (1.0f / 131072.0f);  // 2^-17 relative to the scene's extent
@@ -387,7 +417,9 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     if (tri_order.size() > REF_OFFSET_MASK) { err = "too many triangles"; return RRT_ERR_INVALID; }
 
     hs.tris.resize(tri_order.size());
-    for (size_t k = 0; k < tri_order.size(); ++k) hs.tris[k] = ex.tri_src[tri_order[k]];
+    parallel_for((uint32_t)tri_order.size(), threads, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t k = lo; k < hi; ++k) hs.tris[k] = ex.tri_src[tri_order[k]];
+    });
 
     const rrt_camera& c = d->camera;
     for (int a = 0; a < 3; ++a) {
