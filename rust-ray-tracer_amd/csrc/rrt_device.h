@@ -30,10 +30,34 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
 __device__ __forceinline__ float length_squared(V3 a) { return dot(a, a); }
 __device__ __forceinline__ V3 normalize(V3 a) { return a / sqrtf(dot(a, a)); }
 __device__ __forceinline__ float comp(V3 a, uint32_t axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
+#define RRT_PI 3.14159274101257324f  // std::f32::consts::PI
+#define RRT_INV_PI 0.318309886183790672f
 // Rust f32::signum: 1.0 for +0.0 and positives, -1.0 for -0.0 and negatives, NaN for NaN
 __device__ __forceinline__ float signum(float x) { return x != x ? x : copysignf(1.0f, x); }
 
-#define RRT_PI 3.14159274101257324f  // std::f32::consts::PI
+// Shading arithmetic.  Normalisations and the final path weight use the hardware reciprocal and reciprocal square
+// root (one instruction, 1 ulp) in place of the correctly rounded IEEE sequences (about ten instructions each): an
+// ulp there moves a sample by far less than its Monte-Carlo noise.  Everything that decides WHICH surface a ray
+// meets (the primitive tests, the light's own hit test) and the light pdf, whose 1 - cos(theta_max) cancels
+// leading digits, keep IEEE division and square root, as the reference's f32 arithmetic has them.
+__device__ __forceinline__ float rcp_1ulp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsq_1ulp(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ V3 unit(V3 a) { return a * rsq_1ulp(dot(a, a)); }  // glam normalize, to 1-2 ulp
+
+// (sin, cos) of 2*pi*turn for turn in [0, 1): the nearest quarter turn is removed exactly, then the Cephes
+// single-precision polynomials on [-pi/4, pi/4] (about 1 ulp), then the quadrant is put back.
+__device__ __forceinline__ void sincos_turn(float turn, float& sn, float& cs) {
+    const float q = rintf(turn * 4.0f);
+    const float x = __builtin_fmaf(q, -0.25f, turn) * (2.0f * RRT_PI);  // the subtraction is exact
+    const float z = x * x;
+    const float s = __builtin_fmaf(x * z, __builtin_fmaf(z, __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), x);
+    const float c = __builtin_fmaf(z * z, __builtin_fmaf(z, __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                                   __builtin_fmaf(z, -0.5f, 1.0f));
+    const uint32_t k = (uint32_t)(int)q;
+    const float a = (k & 1u) ? c : s, b = (k & 1u) ? s : c;
+    sn = __uint_as_float(__float_as_uint(a) ^ ((k & 2u) << 30));
+    cs = __uint_as_float(__float_as_uint(b) ^ (((k + 1u) & 2u) << 30));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Counter-based RNG: the i-th draw of sample `s` of pixel `p` under seed `k` is a pure function
@@ -93,9 +117,9 @@ struct Onb {
 };
 __device__ __forceinline__ Onb onb_from_w(V3 n) {
     Onb o;
-    o.w = normalize(n);
+    o.w = unit(n);
     const float sign = copysignf(1.0f, o.w.z);
-    const float a = -1.0f / (sign + o.w.z);
+    const float a = -rcp_1ulp(sign + o.w.z);
     const float b = o.w.x * o.w.y * a;
     o.u = v3(1.0f + sign * o.w.x * o.w.x * a, sign * b, -sign * o.w.x);
     o.v = v3(b, sign + o.w.y * o.w.y * a, -o.w.y);
@@ -431,7 +455,7 @@ __device__ __forceinline__ Surface surface_at(const SceneDev& S, const Best& bes
         const float4 q1 = *reinterpret_cast<const float4*>(&S.tris[idx].e1[0]);
         const float4 q2 = *reinterpret_cast<const float4*>(&S.tris[idx].e2[0]);
         // det > 1e-5 on every accepted hit, so det.signum() == 1 (triangle.rs:42,58)
-        s.n = normalize(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));
+        s.n = unit(cross(v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z)));
         s.material = __float_as_uint(q1.w);
     } else if (kind == KIND_SPHERE) {
         const float4 q0 = *reinterpret_cast<const float4*>(&S.spheres[idx].c[0]);
@@ -510,10 +534,9 @@ __device__ __forceinline__ V3 random_cosine_direction(Rng& rng) {
     const float r1 = rng_f32(rng);
     const float r2 = rng_f32(rng);
     const float z = sqrtf(1.0f - r2);
-    const float phi = 2.0f * RRT_PI * r1;
     const float sr2 = sqrtf(r2);
     float sn, cs;
-    sincosf(phi, &sn, &cs);
+    sincos_turn(r1, sn, cs);  // phi = 2 pi r1
     return v3(cs * sr2, sn * sr2, z);
 }
 
@@ -550,7 +573,7 @@ __device__ __forceinline__ bool shade(const SceneDev& S, const Surface& sf, V3& 
     }
     if (kind == 0u) {  // Lambertian, material/mod.rs:71-84 + mixture sampling, ray.rs:99-120
         const Onb uvw = onb_from_w(sf.n);
-        V3 dir;
+        V3 dir, unit_dir;
         float pdf_val;
         if (S.light_count != 0u) {
             // MixturePDF::generate, pdf.rs:87-94.  The cosine lobe (pdf.rs:14-26,42) and a sphere light
@@ -590,30 +613,29 @@ __device__ __forceinline__ bool shade(const SceneDev& S, const Surface& sf, V3& 
                     z = 1.0f + r2 * (sqrtf(1.0f - sphere_r2_over_d2) - 1.0f);
                     radial = sqrtf(1.0f - z * z);
                 }
-                const float phi = 2.0f * RRT_PI * r1;
                 float sn, cs;
-                sincosf(phi, &sn, &cs);
+                sincos_turn(r1, sn, cs);  // phi = 2 pi r1
                 dir = onb_local(basis, v3(cs * radial, sn * radial, z));
             }
-            const float cosine = dot(normalize(dir), uvw.w);
-            const float cos_pdf = fmaxf(cosine / RRT_PI, 0.0f);
+            unit_dir = unit(dir);
+            const float cos_pdf = fmaxf(dot(unit_dir, uvw.w) * RRT_INV_PI, 0.0f);
             pdf_val = 0.5f * cos_pdf + 0.5f * lights_pdf(S, sf.p, dir);
         } else {
             dir = onb_local(uvw, random_cosine_direction(rng));
-            const float cosine = dot(normalize(dir), uvw.w);
-            pdf_val = fmaxf(cosine / RRT_PI, 0.0f);
+            unit_dir = unit(dir);
+            pdf_val = fmaxf(dot(unit_dir, uvw.w) * RRT_INV_PI, 0.0f);
         }
         pdf_val = fmaxf(pdf_val, 1e-5f);
-        const float s_pdf = fmaxf(dot(sf.n, normalize(dir)) / RRT_PI, 0.0f);
+        const float s_pdf = fmaxf(dot(sf.n, unit_dir) * RRT_INV_PI, 0.0f);
         // emitted == 0 for Lambertian;  L = s_pdf * (albedo * L_next) / pdf_val
-        beta = mulv(beta, (s_pdf * rgb) / pdf_val);
+        beta = mulv(beta, (s_pdf * rcp_1ulp(pdf_val)) * rgb);
         o = sf.p;
         d = dir;
         return true;
     }
     if (kind == 1u) {  // Metal, material/mod.rs:91-108
         const float fuzz = S.mats[sf.material].param;
-        const V3 reflected = reflect(normalize(d), sf.n);
+        const V3 reflected = reflect(unit(d), sf.n);
         const V3 dir = reflected + fuzz * random_in_unit_sphere(rng);
         if (dot(dir, sf.n) > 0.0f) {
             beta = mulv(beta, rgb);
