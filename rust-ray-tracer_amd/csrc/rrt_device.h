@@ -144,9 +144,9 @@ __device__ __forceinline__ bool better(float t, uint32_t id, const Best& b) { re
 // reference src/geometry/triangle.rs:38-69
 __device__ __forceinline__ void test_triangle(const TriRec* __restrict__ tris, uint32_t idx, V3 o, V3 d, float tmin,
                                               uint32_t id_base, int32_t inst, Best& best) {
-    const float4 q0 = *reinterpret_cast<const float4*>(&tris[idx].v0[0]);
-    const float4 q1 = *reinterpret_cast<const float4*>(&tris[idx].e1[0]);
-    const float4 q2 = *reinterpret_cast<const float4*>(&tris[idx].e2[0]);
+    // 48-byte records at a 32-bit byte offset (two shifts) from the uniform base
+    const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + ((idx << 5) + (idx << 4)));
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q1.x, q1.y, q1.z), e2 = v3(q2.x, q2.y, q2.z);
     const V3 pvec = cross(d, e2);
     const float det = dot(e1, pvec);
@@ -331,7 +331,8 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, float tmin, int* s
     const uint32_t rx = T.rx, ry = T.ry, rz = T.rz;
     int cur = T.cur, sp = T.sp;
     while (cur >= 0) {
-        const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
+        // 32-bit byte offset from the uniform base: one shift, and the load takes the base from scalar registers
+        const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + ((uint32_t)cur << 5));
         const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
         if (COUNT) {
             cnt.nodes++;
