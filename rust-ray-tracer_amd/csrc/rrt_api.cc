@@ -327,7 +327,10 @@ rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32
     if ((uint64_t)spp + spp_offset > 0xFFFFFFFFull) return set_err(c, RRT_ERR_INVALID, "rrt_render_device: sample index overflows");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     hipStream_t s = (hipStream_t)stream;
-    uint32_t n_chunks = render_chunks(width, height, spp);
+    // Scenes with a real hierarchy (>= 4096 nodes): paths bounce and walks are long, so items of 8 samples, the
+    // straggler rule and lanes that move on to the next item by themselves pay; on tiny scenes each of them costs.
+    const bool big_scene = c->info.node_count >= 4096u;
+    uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? 8u : 16u);
     if (const char* e = std::getenv("RRT_CHUNKS")) {
         const int v = std::atoi(e);
         if (v >= 1) n_chunks = std::min<uint32_t>((uint32_t)v, spp);
@@ -346,9 +349,13 @@ rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32
     // tuning overrides for experiments: RRT_CHUNKS (above), RRT_NODE_SHARE (0..64)
     RenderTuning tuning;
     if (const char* e = std::getenv("RRT_NODE_SHARE")) tuning.node_share_64ths = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
-    if (c->info.node_count < 4096u) tuning.leave_walk = 0u;
+    if (!big_scene) {
+        tuning.leave_walk = 0u;
+        tuning.overlap_items = 0u;
+    }
     if (const char* e = std::getenv("RRT_LEAVE_WALK")) tuning.leave_walk = (uint32_t)std::max(0, std::min(63, std::atoi(e)));
     if (const char* e = std::getenv("RRT_LEAVE_READY")) tuning.leave_ready = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+    if (const char* e = std::getenv("RRT_OVERLAP_ITEMS")) tuning.overlap_items = std::atoi(e) != 0 ? 1u : 0u;
     RRT_HIP(c, hipMemsetAsync(c->d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
     RRT_HIP(c, launch_render(c->sdev, width, height, spp, spp_offset, d_accum, c->d_partial, n_chunks, c->d_counters,

@@ -10,7 +10,7 @@
 namespace rrt {
 
 // Number of sample chunks a frame of `spp` samples per pixel is cut into (work item = tile x chunk).
-uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp);
+uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t samples_per_item);
 
 // Share (in 64ths) of the walking lanes that must be descending for a node pass to run; 40/64 measured best
 // on MI355X for both the 968-triangle and the 1M-triangle scene.
@@ -28,6 +28,9 @@ struct RenderTuning {
     // pass -- the library therefore switches it off (leave_walk = 0) for BVHs of fewer than 4096 nodes.
     uint32_t leave_walk = 6u;
     uint32_t leave_ready = 16u;
+    // Render kernel: a lane that has finished its pixel of the wave's current work item starts on the wave's next
+    // item at once (1) or waits for the other lanes (0).
+    uint32_t overlap_items = 1u;
 };
 
 // d_counters: 7 x u64 in device memory {rays, node visits, primitive tests, wave-level node passes, primitive

@@ -37,6 +37,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
     __shared__ int s_stack[STACK_DEPTH * RENDER_BLOCK];
+    __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 16];  // per wavefront: the records of its two work items
     const uint32_t lane = threadIdx.x & 63u;
     int* stack = s_stack + threadIdx.x;
     const uint32_t width = G.width, height = G.height;
@@ -47,15 +48,15 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
     unsigned long long slots_done = 0ull, slots_leaf = 0ull;  // lane 0, COUNT only
     uint32_t q = blockIdx.x % N_QUEUES;
     uint32_t exhausted = 0;
-    // A ticket is always drawn one item ahead, so that the round trip of the atomic overlaps the rendering
-    // of the current item.  Every drawn ticket is resolved by the wave that drew it before that wave exits.
+    // A ticket is always drawn one item ahead, so that the round trip of the atomic overlaps rendering.
+    // Every drawn ticket is resolved by the wave that drew it before that wave exits.
     unsigned int drawn = 0;
     if (lane == 0) drawn = atomicAdd(&heads[q], 1u);
-
-    for (;;) {
-        // ---- next work item: own queue first, then the others' leftovers
-        uint32_t work = 0xFFFFFFFFu;
-        for (;;) {
+    // Next work item of this wave (own queue first, then the others' leftovers); NO_WORK once every queue is empty.
+    constexpr uint32_t NO_WORK = 0xFFFFFFFFu;
+    auto draw = [&]() -> uint32_t {
+        uint32_t work = NO_WORK;
+        while (exhausted < N_QUEUES) {
             const unsigned int ticket = __builtin_amdgcn_readfirstlane(drawn);
             const uint32_t b = queue_begin(q, G.n_work), e = queue_begin(q + 1u, G.n_work);
             if (ticket < e - b) {
@@ -66,110 +67,162 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
             if (++exhausted >= N_QUEUES) break;
             if (lane == 0) drawn = atomicAdd(&heads[q], 1u);
         }
-        if (work == 0xFFFFFFFFu) break;  // every queue is empty: this wave is done
-        if (lane == 0) drawn = atomicAdd(&heads[q], 1u);
+        if (work != NO_WORK && lane == 0) drawn = atomicAdd(&heads[q], 1u);
+        return work;
+    };
 
-        const uint32_t tile = work / G.n_chunks, chunk = work % G.n_chunks;
-        const uint32_t tx = tile % G.tiles_x, ty = tile / G.tiles_x;
-        const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
-        const bool inside = x < width && y < height;
-        // samples [first, first + spp) of this chunk, as absolute sample indices
-        const uint32_t first = chunk * G.chunk_spp;
-        const uint32_t spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
-        const uint32_t spp_offset = G.spp_offset + first;
-        const uint32_t pixel = y * width + x;
+    // The wave holds two items, the current one and the next one.  A lane that has finished its pixel of the
+    // current item moves on to the next one by itself, so the lanes whose pixels took few rays do not wait for the
+    // others (a lane that is done with both does).  When no lane is left on the current item, the next one takes
+    // its place and another is drawn.  Every (item, pixel) sum is still formed by one lane in sample order,
+    // whatever the interleaving, so the image does not depend on it.
+    // The two items' records live in LDS (x0, y0, chunk, sample count, first sample index; count 0 = no item): a
+    // lane reads the one it moves to, the wave writes one when it draws an item.
+    uint32_t* items = s_items + (threadIdx.x >> 6) * 16u;
+    uint32_t cur_slot = 0u;    // record of the current item; the next item's is the other one
+    bool next_valid = false;
+    auto draw_into = [&](uint32_t slot) -> bool {
+        const uint32_t work = draw();
+        uint32_t x0 = 0u, y0 = 0u, chunk = 0u, n_spp = 0u, first_sample = 0u;
+        if (work != NO_WORK) {
+            const uint32_t tile = work / G.n_chunks;
+            chunk = work % G.n_chunks;
+            const uint32_t first = chunk * G.chunk_spp;  // samples [first, first + n_spp) as absolute sample indices
+            x0 = (tile % G.tiles_x) * 8u;
+            y0 = (tile / G.tiles_x) * 8u;
+            n_spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
+            first_sample = G.spp_offset + first;
+        }
+        if (lane == 0u) {
+            uint32_t* rec = items + slot * 8u;
+            rec[0] = x0; rec[1] = y0; rec[2] = chunk; rec[3] = n_spp; rec[4] = first_sample;
+        }
+        return work != NO_WORK;
+    };
+    draw_into(0u);
+    next_valid = draw_into(1u);
 
-        V3 sum = v3(0.f, 0.f, 0.f);
-        uint32_t s = inside ? 0u : spp;  // sample counter of this lane
-        bool has_ray = s < spp;          // this lane has a ray in flight (being walked, or waiting to be shaded)
-        V3 o, d, beta, radiance;
-        uint32_t depth = 0;
-        Rng rng;
-        Trav T;
-        T.cur = REF_DONE;
-        T.sp = 1;
-        if (has_ray) {
-            rng = rng_init(S.seed, pixel, spp_offset + s);
-            const float u = (float)x + rng_f32(rng);  // main.rs:92-93
-            const float v = (float)y + rng_f32(rng);
-            rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
-            camera_ray(S.cam, u, v, width, height, o, d);
-            beta = v3(1.f, 1.f, 1.f);
-            radiance = v3(0.f, 0.f, 0.f);
-            depth = S.max_depth;
-            trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
+    // per lane: `stage` = which of the two items it is on (0: current, 1: next, 2: done with both), + 4 once it
+    // has taken its pixel of that item; then its place in the item
+    uint32_t stage = 0u;
+    uint32_t x = 0, y = 0, pixel = 0, item_chunk = 0, item_spp = 0, item_first = 0;
+    uint32_t s = 0;          // sample counter within the item
+    bool has_ray = false;    // a ray is in flight (being walked, or waiting to be shaded)
+    V3 sum = v3(0.f, 0.f, 0.f);
+    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), beta = v3(0.f, 0.f, 0.f), radiance = v3(0.f, 0.f, 0.f);
+    uint32_t depth = 0;
+    Rng rng = {0u, 0u, 0u};
+    Trav T;
+    T.cur = REF_DONE;
+    T.sp = 1;
+
+    for (;;) {
+        // ---- item rotation (touches nothing of a lane but its stage)
+        bool out_of_work = false;
+        while (__ballot((stage & 3u) == 0u) == 0ull) {
+            if (!next_valid) {
+                out_of_work = true;  // nobody on the current item and no next item: every lane is done
+                break;
+            }
+            stage--;
+            next_valid = draw_into(cur_slot);  // the old current item's record is free
+            cur_slot ^= 1u;
+        }
+        if (out_of_work) break;
+
+        // ---- walk phase: node passes and leaf passes alternate until every lane's walk is complete.
+        // A pass costs the same however many lanes take part, so a node pass only runs (and only keeps
+        // running) while a fair share of the walking lanes is descending; below that share the lanes
+        // waiting at leaves get their primitive test first.  (Measured on MI355X: the share rule raises the
+        // lanes active per node pass from 28 % to 41 % on the 1M-triangle scene.)
+        for (;;) {
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(T.cur != REF_DONE));
+            if (n_walk == 0u) break;
+            // the last few walkers of a trip are left to finish in the next one, once enough lanes wait to shade
+            if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
+            const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
+            const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
+            if (n_desc == n_walk || n_desc >= share) {
+                if (COUNT) {
+                    // idle lane slots of this node pass, by what the idle lanes are waiting for
+                    // (the pass is as long as the lane that stayed in it longest)
+                    const uint32_t nodes0 = cnt.nodes;
+                    trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                    uint32_t steps = cnt.nodes - nodes0;
+                    for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
+                    if (lane == 0u) {
+                        slots_done += (unsigned long long)steps * (64u - n_walk);
+                        slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
+                    }
+                } else {
+                    trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                }
+            }
+            if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
         }
 
-        for (;;) {
-            // ---- walk phase: node passes and leaf passes alternate until every lane's walk is complete.
-            // A pass costs the same however many lanes take part, so a node pass only runs (and only keeps
-            // running) while a fair share of the walking lanes is descending; below that share the lanes
-            // waiting at leaves get their primitive test first.  (Measured on MI355X: the share rule raises the
-            // lanes active per node pass from 28 % to 41 % on the 1M-triangle scene.  Leaving the walk phase
-            // early to shade finished lanes did not pay: shading passes with few lanes cost more than they save.)
-            for (;;) {
-                const uint32_t n_walk = (uint32_t)__popcll(__ballot(T.cur != REF_DONE));
-                if (n_walk == 0u) break;
-                // the last few walkers of a trip are left to finish in the next one, once enough lanes wait to shade
-                if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
-                const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
-                const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
-                if (n_desc == n_walk || n_desc >= share) {
-                    if (COUNT) {
-                        // idle lane slots of this node pass, by what the idle lanes are waiting for
-                        // (the pass is as long as the lane that stayed in it longest)
-                        const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
-                        uint32_t steps = cnt.nodes - nodes0;
-                        for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
-                        if (lane == 0u) {
-                            slots_done += (unsigned long long)steps * (64u - n_walk);
-                            slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
-                        }
-                    } else {
-                        trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
-                    }
-                }
-                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
-            }
-            // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
-            if (has_ray && T.cur == REF_DONE) {
+        // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
+        // next sample, a lane whose item ended (or that has none yet) takes its pixel of the item it is due for
+        const bool shade_now = has_ray && T.cur == REF_DONE;
+        bool take = stage == 0u || (stage == 1u && G.overlap_items != 0u);
+        if (shade_now || take) {
+            bool alive = false;
+            if (shade_now) {
                 n_rays++;
                 if (COUNT && first_active_lane()) cnt.wave_shade++;
-                bool alive;
                 if (T.best.id == 0xFFFFFFFFu) {
                     radiance = radiance + mulv(beta, bg);  // ray.rs:126
-                    alive = false;
                 } else {
                     const Surface sf = surface_at(S, T.best, o, d);
                     alive = shade(S, sf, o, d, beta, radiance, rng);
                 }
                 depth--;
                 if (depth == 0u) alive = false;  // ray.rs:85-87: depth 0 contributes black
-                if (!alive) {
+            }
+            if (!alive) {  // the path ended, or the lane had none
+                bool start = shade_now;
+                if (shade_now) {
                     sum = sum + radiance;  // main.rs:95
                     s++;
-                    if (s < spp) {
-                        rng = rng_init(S.seed, pixel, spp_offset + s);
-                        const float u = (float)x + rng_f32(rng);
-                        const float v = (float)y + rng_f32(rng);
-                        rng.ctr++;
-                        camera_ray(S.cam, u, v, width, height, o, d);
-                        beta = v3(1.f, 1.f, 1.f);
-                        radiance = v3(0.f, 0.f, 0.f);
-                        depth = S.max_depth;
-                    } else {
+                    if (s >= item_spp) {  // this lane's part of the item is complete: one 12-byte store
+                        float* px = out + 3ull * ((size_t)item_chunk * width * height + pixel);
+                        px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
                         has_ray = false;
+                        start = false;
+                        stage = (stage & 3u) + 1u;
+                        take = stage == 1u && G.overlap_items != 0u;
                     }
                 }
-                if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
+                if (take) {
+                    const uint32_t* rec = items + (stage == 0u ? cur_slot : cur_slot ^ 1u) * 8u;
+                    const uint32_t px_x = rec[0] + (lane & 7u), px_y = rec[1] + (lane >> 3);
+                    const uint32_t n_spp = rec[3];
+                    if (px_x < width && px_y < height && n_spp != 0u) {
+                        x = px_x; y = px_y; pixel = px_y * width + px_x;
+                        item_chunk = rec[2];
+                        item_spp = n_spp;
+                        item_first = rec[4];
+                        s = 0u;
+                        sum = v3(0.f, 0.f, 0.f);
+                        stage += 4u;
+                        start = true;
+                    } else {
+                        stage++;  // nothing for this lane in that item
+                    }
+                }
+                if (start) {
+                    rng = rng_init(S.seed, pixel, item_first + s);
+                    const float u = (float)x + rng_f32(rng);  // main.rs:92-93
+                    const float v = (float)y + rng_f32(rng);
+                    rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
+                    camera_ray(S.cam, u, v, width, height, o, d);
+                    beta = v3(1.f, 1.f, 1.f);
+                    radiance = v3(0.f, 0.f, 0.f);
+                    depth = S.max_depth;
+                    has_ray = true;
+                }
             }
-            if (__ballot(has_ray) == 0ull) break;  // every lane has rendered all samples of this item
-        }
-
-        if (inside) {
-            float* px = out + 3ull * ((size_t)chunk * width * height + pixel);
-            px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
+            if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
         }
     }
 
@@ -345,13 +398,15 @@ __global__ void k_reduce_chunks(const float* __restrict__ partial, uint32_t n_fl
 
 // ---- launchers --------------------------------------------------------------------------------
 
-uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp) {
-    // Measured on MI355X: about 16 samples per item amortise the queue ticket and the 12-byte-per-pixel
-    // write of an item; small frames get more, smaller items so that every resident wave finds a few
+uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t samples_per_item) {
+    // Measured on MI355X: items of about 16 trips (16 samples where most paths end at the first ray, 8 where they
+    // bounce) amortise the queue ticket and the 12-byte-per-pixel write of an item and still spread an expensive
+    // tile over many CUs; small frames get more, smaller items so that every resident wave finds a few
     // (target: 4 items per wavefront slot of the chip, 256 CUs x 20 wavefronts).  Never fewer than 4
     // samples per item, never more than 32 partial images.
     const uint64_t n_tiles = (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u);
-    uint64_t n = (spp + 15u) / 16u;
+    if (samples_per_item == 0u) samples_per_item = 16u;
+    uint64_t n = (spp + samples_per_item - 1u) / samples_per_item;
     const uint64_t for_balance = (4ull * 256ull * 20ull + n_tiles - 1u) / n_tiles;
     if (n < for_balance) n = for_balance;
     if (n > spp / 4u) n = spp / 4u;
@@ -398,6 +453,7 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     G.node_share_64ths = tuning.node_share_64ths;
     G.leave_walk = tuning.leave_walk;
     G.leave_ready = tuning.leave_ready;
+    G.overlap_items = tuning.overlap_items;
     float* out = n_chunks > 1u ? d_partial : d_accum;
     const bool inst = S.has_instances != 0u;
     hipError_t e;

@@ -161,15 +161,18 @@ struct RenderGeom {
     uint32_t node_share_64ths;  // a node pass runs while at least this share (in 64ths) of the walking lanes descends
     uint32_t leave_walk;        // a trip's walk phase ends when at most this many lanes still walk ...
     uint32_t leave_ready;       // ... and at least this many lanes wait to shade (leave_walk 0: walk to the end)
+    uint32_t overlap_items;     // lanes move on to the wave's next item by themselves (1) or together (0)
 };
 
 // Per-lane traversal stack entries (LDS).  One inner-node step pushes at most one entry, so the stack never
 // holds more than (tree depth) entries plus the bottom marker and, for instanced scenes, one exit marker;
-// the builder bounds the combined depth of top level + bottom level to MAX_TREE_DEPTH.  40 entries x 256 lanes x
-// 4 bytes = 40 KB per workgroup: four workgroups fill the 160 KB of LDS of a CU, and four are as fast as five
-// (measured); the depth leaves room for the linear BVHs of the GPU builder (31 levels for ten million triangles).
-static constexpr int STACK_DEPTH = 40;
+// the builder bounds the combined depth of top level + bottom level to MAX_TREE_DEPTH.  39 entries x 256 lanes x
+// 4 bytes = 39 KB per workgroup, which leaves the render kernel 1 KB for its work-item records: four workgroups
+// fill the 160 KB of LDS of a CU, and four are as fast as five (measured); the depth leaves room for the linear
+// BVHs of the GPU builder (31 levels for ten million triangles).
+static constexpr int STACK_DEPTH = 39;
 static constexpr uint32_t MAX_TREE_DEPTH = 37;
+static_assert(MAX_TREE_DEPTH + 2 <= (uint32_t)STACK_DEPTH, "stack holds the deepest walk plus its two markers");
 
 }  // namespace rrt
 #endif
