@@ -28,8 +28,9 @@ struct RenderTuning {
     // pass -- the library therefore switches it off (leave_walk = 0) for BVHs of fewer than 4096 nodes.
     uint32_t leave_walk = 6u;
     uint32_t leave_ready = 16u;
-    // Render kernel: a lane that has finished its pixel of the wave's current work item starts on the wave's next
-    // item at once (1) or waits for the other lanes (0).
+    // Render kernel: the pipelined form (1: a wavefront holds two work items, and a lane that has finished its pixel
+    // of the current one starts on the next one at once) or the item-at-a-time form (0).  Measured on MI355X: the
+    // pipelined form is 5-9 % faster on the large scenes and 6 % slower on the 968-triangle one.
     uint32_t overlap_items = 1u;
 };
 

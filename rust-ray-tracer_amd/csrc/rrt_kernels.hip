@@ -8,6 +8,10 @@
 // parked waiting for the longest path in the wave.  The radiance sum stays in registers and is written
 // once per item (12 bytes per pixel).  Traversal stacks live in LDS (STACK_DEPTH dwords per lane, laid
 // out [entry][thread] so that a wave access touches 64 consecutive banks).
+// The kernel has two forms of the loop over items (template parameter PIPELINED): one item at a time, or two
+// items in flight per wavefront with every lane moving from one to the next by itself.  The two forms are kept as
+// separate texts on purpose: written over shared helpers the pipelined form compiled to 3-20 % slower code
+// (register allocation at the 128-VGPR limit of four waves per SIMD).
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
@@ -32,7 +36,7 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
     return (uint32_t)(((unsigned long long)q * n_work) / N_QUEUES);
 }
 
-template <bool INST, bool COUNT>
+template <bool INST, bool COUNT, bool PIPELINED>
 __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
@@ -71,158 +75,270 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
         return work;
     };
 
-    // The wave holds two items, the current one and the next one.  A lane that has finished its pixel of the
-    // current item moves on to the next one by itself, so the lanes whose pixels took few rays do not wait for the
-    // others (a lane that is done with both does).  When no lane is left on the current item, the next one takes
-    // its place and another is drawn.  Every (item, pixel) sum is still formed by one lane in sample order,
-    // whatever the interleaving, so the image does not depend on it.
-    // The two items' records live in LDS (x0, y0, chunk, sample count, first sample index; count 0 = no item): a
-    // lane reads the one it moves to, the wave writes one when it draws an item.
-    uint32_t* items = s_items + (threadIdx.x >> 6) * 16u;
-    uint32_t cur_slot = 0u;    // record of the current item; the next item's is the other one
-    bool next_valid = false;
-    auto draw_into = [&](uint32_t slot) -> bool {
-        const uint32_t work = draw();
-        uint32_t x0 = 0u, y0 = 0u, chunk = 0u, n_spp = 0u, first_sample = 0u;
-        if (work != NO_WORK) {
-            const uint32_t tile = work / G.n_chunks;
-            chunk = work % G.n_chunks;
-            const uint32_t first = chunk * G.chunk_spp;  // samples [first, first + n_spp) as absolute sample indices
-            x0 = (tile % G.tiles_x) * 8u;
-            y0 = (tile / G.tiles_x) * 8u;
-            n_spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
-            first_sample = G.spp_offset + first;
-        }
-        if (lane == 0u) {
-            uint32_t* rec = items + slot * 8u;
-            rec[0] = x0; rec[1] = y0; rec[2] = chunk; rec[3] = n_spp; rec[4] = first_sample;
-        }
-        return work != NO_WORK;
-    };
-    draw_into(0u);
-    next_valid = draw_into(1u);
-
-    // per lane: `stage` = which of the two items it is on (0: current, 1: next, 2: done with both), + 4 once it
-    // has taken its pixel of that item; then its place in the item
-    uint32_t stage = 0u;
-    uint32_t x = 0, y = 0, pixel = 0, item_chunk = 0, item_spp = 0, item_first = 0;
-    uint32_t s = 0;          // sample counter within the item
-    bool has_ray = false;    // a ray is in flight (being walked, or waiting to be shaded)
-    V3 sum = v3(0.f, 0.f, 0.f);
-    V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), beta = v3(0.f, 0.f, 0.f), radiance = v3(0.f, 0.f, 0.f);
-    uint32_t depth = 0;
-    Rng rng = {0u, 0u, 0u};
-    Trav T;
-    T.cur = REF_DONE;
-    T.sp = 1;
-
-    for (;;) {
-        // ---- item rotation (touches nothing of a lane but its stage)
-        bool out_of_work = false;
-        while (__ballot((stage & 3u) == 0u) == 0ull) {
-            if (!next_valid) {
-                out_of_work = true;  // nobody on the current item and no next item: every lane is done
-                break;
-            }
-            stage--;
-            next_valid = draw_into(cur_slot);  // the old current item's record is free
-            cur_slot ^= 1u;
-        }
-        if (out_of_work) break;
-
-        // ---- walk phase: node passes and leaf passes alternate until every lane's walk is complete.
-        // A pass costs the same however many lanes take part, so a node pass only runs (and only keeps
-        // running) while a fair share of the walking lanes is descending; below that share the lanes
-        // waiting at leaves get their primitive test first.  (Measured on MI355X: the share rule raises the
-        // lanes active per node pass from 28 % to 41 % on the 1M-triangle scene.)
+    if (!PIPELINED) {
+        // One item at a time: the lanes start an item together and wait for its last path.  The form for
+        // scenes whose trips are short (a handful of node steps, mostly first-ray misses), where the
+        // bookkeeping of the pipelined form below costs more than the waiting it removes.
         for (;;) {
-            const uint32_t n_walk = (uint32_t)__popcll(__ballot(T.cur != REF_DONE));
-            if (n_walk == 0u) break;
-            // the last few walkers of a trip are left to finish in the next one, once enough lanes wait to shade
-            if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
-            const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
-            const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
-            if (n_desc == n_walk || n_desc >= share) {
-                if (COUNT) {
-                    // idle lane slots of this node pass, by what the idle lanes are waiting for
-                    // (the pass is as long as the lane that stayed in it longest)
-                    const uint32_t nodes0 = cnt.nodes;
-                    trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
-                    uint32_t steps = cnt.nodes - nodes0;
-                    for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
-                    if (lane == 0u) {
-                        slots_done += (unsigned long long)steps * (64u - n_walk);
-                        slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
-                    }
-                } else {
-                    trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
-                }
-            }
-            if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
-        }
+            const uint32_t work = draw();
+            if (work == NO_WORK) break;  // every queue is empty: this wave is done
+            const uint32_t tile = work / G.n_chunks, chunk = work % G.n_chunks;
+            const uint32_t tx = tile % G.tiles_x, ty = tile / G.tiles_x;
+            const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+            const bool inside = x < width && y < height;
+            // samples [first, first + spp) of this chunk, as absolute sample indices
+            const uint32_t first = chunk * G.chunk_spp;
+            const uint32_t spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
+            const uint32_t spp_offset = G.spp_offset + first;
+            const uint32_t pixel = y * width + x;
 
-        // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
-        // next sample, a lane whose item ended (or that has none yet) takes its pixel of the item it is due for
-        const bool shade_now = has_ray && T.cur == REF_DONE;
-        bool take = stage == 0u || (stage == 1u && G.overlap_items != 0u);
-        if (shade_now || take) {
-            bool alive = false;
-            if (shade_now) {
-                n_rays++;
-                if (COUNT && first_active_lane()) cnt.wave_shade++;
-                if (T.best.id == 0xFFFFFFFFu) {
-                    radiance = radiance + mulv(beta, bg);  // ray.rs:126
-                } else {
-                    const Surface sf = surface_at(S, T.best, o, d);
-                    alive = shade(S, sf, o, d, beta, radiance, rng);
-                }
-                depth--;
-                if (depth == 0u) alive = false;  // ray.rs:85-87: depth 0 contributes black
+            V3 sum = v3(0.f, 0.f, 0.f);
+            uint32_t s = inside ? 0u : spp;  // sample counter of this lane
+            bool has_ray = s < spp;          // this lane has a ray in flight (being walked, or waiting to be shaded)
+            V3 o, d, beta, radiance;
+            uint32_t depth = 0;
+            Rng rng;
+            Trav T;
+            T.cur = REF_DONE;
+            T.sp = 1;
+            if (has_ray) {
+                rng = rng_init(S.seed, pixel, spp_offset + s);
+                const float u = (float)x + rng_f32(rng);  // main.rs:92-93
+                const float v = (float)y + rng_f32(rng);
+                rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
+                camera_ray(S.cam, u, v, width, height, o, d);
+                beta = v3(1.f, 1.f, 1.f);
+                radiance = v3(0.f, 0.f, 0.f);
+                depth = S.max_depth;
+                trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
             }
-            if (!alive) {  // the path ended, or the lane had none
-                bool start = shade_now;
-                if (shade_now) {
-                    sum = sum + radiance;  // main.rs:95
-                    s++;
-                    if (s >= item_spp) {  // this lane's part of the item is complete: one 12-byte store
-                        float* px = out + 3ull * ((size_t)item_chunk * width * height + pixel);
-                        px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
-                        has_ray = false;
-                        start = false;
-                        stage = (stage & 3u) + 1u;
-                        take = stage == 1u && G.overlap_items != 0u;
+
+            for (;;) {
+                // ---- walk phase: node passes and leaf passes alternate until every lane's walk is complete.
+                // A pass costs the same however many lanes take part, so a node pass only runs (and only keeps
+                // running) while a fair share of the walking lanes is descending; below that share the lanes
+                // waiting at leaves get their primitive test first.  (Measured on MI355X: the share rule raises the
+                // lanes active per node pass from 28 % to 41 % on the 1M-triangle scene.  Leaving the walk phase
+                // early to shade finished lanes did not pay: shading passes with few lanes cost more than they save.)
+                for (;;) {
+                    const uint32_t n_walk = (uint32_t)__popcll(__ballot(T.cur != REF_DONE));
+                    if (n_walk == 0u) break;
+                    // the last few walkers of a trip are left to finish in the next one, once enough lanes wait to shade
+                    if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
+                    const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
+                    const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
+                    if (n_desc == n_walk || n_desc >= share) {
+                        if (COUNT) {
+                            // idle lane slots of this node pass, by what the idle lanes are waiting for
+                            // (the pass is as long as the lane that stayed in it longest)
+                            const uint32_t nodes0 = cnt.nodes;
+                            trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                            uint32_t steps = cnt.nodes - nodes0;
+                            for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
+                            if (lane == 0u) {
+                                slots_done += (unsigned long long)steps * (64u - n_walk);
+                                slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
+                            }
+                        } else {
+                            trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                        }
                     }
+                    if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
                 }
-                if (take) {
-                    const uint32_t* rec = items + (stage == 0u ? cur_slot : cur_slot ^ 1u) * 8u;
-                    const uint32_t px_x = rec[0] + (lane & 7u), px_y = rec[1] + (lane >> 3);
-                    const uint32_t n_spp = rec[3];
-                    if (px_x < width && px_y < height && n_spp != 0u) {
-                        x = px_x; y = px_y; pixel = px_y * width + px_x;
-                        item_chunk = rec[2];
-                        item_spp = n_spp;
-                        item_first = rec[4];
-                        s = 0u;
-                        sum = v3(0.f, 0.f, 0.f);
-                        stage += 4u;
-                        start = true;
+                // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
+                if (has_ray && T.cur == REF_DONE) {
+                    n_rays++;
+                    if (COUNT && first_active_lane()) cnt.wave_shade++;
+                    bool alive;
+                    if (T.best.id == 0xFFFFFFFFu) {
+                        radiance = radiance + mulv(beta, bg);  // ray.rs:126
+                        alive = false;
                     } else {
-                        stage++;  // nothing for this lane in that item
+                        const Surface sf = surface_at(S, T.best, o, d);
+                        alive = shade(S, sf, o, d, beta, radiance, rng);
+                    }
+                    depth--;
+                    if (depth == 0u) alive = false;  // ray.rs:85-87: depth 0 contributes black
+                    if (!alive) {
+                        sum = sum + radiance;  // main.rs:95
+                        s++;
+                        if (s < spp) {
+                            rng = rng_init(S.seed, pixel, spp_offset + s);
+                            const float u = (float)x + rng_f32(rng);
+                            const float v = (float)y + rng_f32(rng);
+                            rng.ctr++;
+                            camera_ray(S.cam, u, v, width, height, o, d);
+                            beta = v3(1.f, 1.f, 1.f);
+                            radiance = v3(0.f, 0.f, 0.f);
+                            depth = S.max_depth;
+                        } else {
+                            has_ray = false;
+                        }
+                    }
+                    if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
+                }
+                if (__ballot(has_ray) == 0ull) break;  // every lane has rendered all samples of this item
+            }
+
+            if (inside) {
+                float* px = out + 3ull * ((size_t)chunk * width * height + pixel);
+                px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
+            }
+        }
+    } else {
+        // The wave holds two items, the current one and the next one.  A lane that has finished its pixel of the
+        // current item moves on to the next one by itself, so the lanes whose pixels took few rays do not wait for the
+        // others (a lane that is done with both does).  When no lane is left on the current item, the next one takes
+        // its place and another is drawn.  Every (item, pixel) sum is still formed by one lane in sample order,
+        // whatever the interleaving, so the image does not depend on it.
+        // The two items' records live in LDS (x0, y0, chunk, sample count, first sample index; count 0 = no item): a
+        // lane reads the one it moves to, the wave writes one when it draws an item.
+        uint32_t* items = s_items + (threadIdx.x >> 6) * 16u;
+        uint32_t cur_slot = 0u;    // record of the current item; the next item's is the other one
+        bool next_valid = false;
+        auto draw_into = [&](uint32_t slot) -> bool {
+            const uint32_t work = draw();
+            uint32_t x0 = 0u, y0 = 0u, chunk = 0u, n_spp = 0u, first_sample = 0u;
+            if (work != NO_WORK) {
+                const uint32_t tile = work / G.n_chunks;
+                chunk = work % G.n_chunks;
+                const uint32_t first = chunk * G.chunk_spp;  // samples [first, first + n_spp) as absolute sample indices
+                x0 = (tile % G.tiles_x) * 8u;
+                y0 = (tile / G.tiles_x) * 8u;
+                n_spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
+                first_sample = G.spp_offset + first;
+            }
+            if (lane == 0u) {
+                uint32_t* rec = items + slot * 8u;
+                rec[0] = x0; rec[1] = y0; rec[2] = chunk; rec[3] = n_spp; rec[4] = first_sample;
+            }
+            return work != NO_WORK;
+        };
+        draw_into(0u);
+        next_valid = draw_into(1u);
+
+        // per lane: `stage` = which of the two items it is on (0: current, 1: next, 2: done with both), + 4 once it
+        // has taken its pixel of that item; then its place in the item
+        uint32_t stage = 0u;
+        uint32_t x = 0, y = 0, pixel = 0, item_chunk = 0, item_spp = 0, item_first = 0;
+        uint32_t s = 0;          // sample counter within the item
+        bool has_ray = false;    // a ray is in flight (being walked, or waiting to be shaded)
+        V3 sum = v3(0.f, 0.f, 0.f);
+        V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), beta = v3(0.f, 0.f, 0.f), radiance = v3(0.f, 0.f, 0.f);
+        uint32_t depth = 0;
+        Rng rng = {0u, 0u, 0u};
+        Trav T;
+        T.cur = REF_DONE;
+        T.sp = 1;
+
+        for (;;) {
+            // ---- item rotation (touches nothing of a lane but its stage)
+            bool out_of_work = false;
+            while (__ballot((stage & 3u) == 0u) == 0ull) {
+                if (!next_valid) {
+                    out_of_work = true;  // nobody on the current item and no next item: every lane is done
+                    break;
+                }
+                stage--;
+                next_valid = draw_into(cur_slot);  // the old current item's record is free
+                cur_slot ^= 1u;
+            }
+            if (out_of_work) break;
+
+            // ---- walk phase: node passes and leaf passes alternate until every lane's walk is complete.
+            // A pass costs the same however many lanes take part, so a node pass only runs (and only keeps
+            // running) while a fair share of the walking lanes is descending; below that share the lanes
+            // waiting at leaves get their primitive test first.  (Measured on MI355X: the share rule raises the
+            // lanes active per node pass from 28 % to 41 % on the 1M-triangle scene.)
+            for (;;) {
+                const uint32_t n_walk = (uint32_t)__popcll(__ballot(T.cur != REF_DONE));
+                if (n_walk == 0u) break;
+                // the last few walkers of a trip are left to finish in the next one, once enough lanes wait to shade
+                if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
+                const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
+                const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
+                if (n_desc == n_walk || n_desc >= share) {
+                    if (COUNT) {
+                        // idle lane slots of this node pass, by what the idle lanes are waiting for
+                        // (the pass is as long as the lane that stayed in it longest)
+                        const uint32_t nodes0 = cnt.nodes;
+                        trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                        uint32_t steps = cnt.nodes - nodes0;
+                        for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
+                        if (lane == 0u) {
+                            slots_done += (unsigned long long)steps * (64u - n_walk);
+                            slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
+                        }
+                    } else {
+                        trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
                     }
                 }
-                if (start) {
-                    rng = rng_init(S.seed, pixel, item_first + s);
-                    const float u = (float)x + rng_f32(rng);  // main.rs:92-93
-                    const float v = (float)y + rng_f32(rng);
-                    rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
-                    camera_ray(S.cam, u, v, width, height, o, d);
-                    beta = v3(1.f, 1.f, 1.f);
-                    radiance = v3(0.f, 0.f, 0.f);
-                    depth = S.max_depth;
-                    has_ray = true;
-                }
+                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
             }
-            if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
+
+            // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
+            // next sample, a lane whose item ended (or that has none yet) takes its pixel of the item it is due for
+            const bool shade_now = has_ray && T.cur == REF_DONE;
+            bool take = stage == 0u || stage == 1u;  // on an item without having taken its pixel of it
+            if (shade_now || take) {
+                bool alive = false;
+                if (shade_now) {
+                    n_rays++;
+                    if (COUNT && first_active_lane()) cnt.wave_shade++;
+                    if (T.best.id == 0xFFFFFFFFu) {
+                        radiance = radiance + mulv(beta, bg);  // ray.rs:126
+                    } else {
+                        const Surface sf = surface_at(S, T.best, o, d);
+                        alive = shade(S, sf, o, d, beta, radiance, rng);
+                    }
+                    depth--;
+                    if (depth == 0u) alive = false;  // ray.rs:85-87: depth 0 contributes black
+                }
+                if (!alive) {  // the path ended, or the lane had none
+                    bool start = shade_now;
+                    if (shade_now) {
+                        sum = sum + radiance;  // main.rs:95
+                        s++;
+                        if (s >= item_spp) {  // this lane's part of the item is complete: one 12-byte store
+                            float* px = out + 3ull * ((size_t)item_chunk * width * height + pixel);
+                            px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
+                            has_ray = false;
+                            start = false;
+                            stage = (stage & 3u) + 1u;
+                            take = stage == 1u;
+                        }
+                    }
+                    if (take) {
+                        const uint32_t* rec = items + (stage == 0u ? cur_slot : cur_slot ^ 1u) * 8u;
+                        const uint32_t px_x = rec[0] + (lane & 7u), px_y = rec[1] + (lane >> 3);
+                        const uint32_t n_spp = rec[3];
+                        if (px_x < width && px_y < height && n_spp != 0u) {
+                            x = px_x; y = px_y; pixel = px_y * width + px_x;
+                            item_chunk = rec[2];
+                            item_spp = n_spp;
+                            item_first = rec[4];
+                            s = 0u;
+                            sum = v3(0.f, 0.f, 0.f);
+                            stage += 4u;
+                            start = true;
+                        } else {
+                            stage++;  // nothing for this lane in that item
+                        }
+                    }
+                    if (start) {
+                        rng = rng_init(S.seed, pixel, item_first + s);
+                        const float u = (float)x + rng_f32(rng);  // main.rs:92-93
+                        const float v = (float)y + rng_f32(rng);
+                        rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
+                        camera_ray(S.cam, u, v, width, height, o, d);
+                        beta = v3(1.f, 1.f, 1.f);
+                        radiance = v3(0.f, 0.f, 0.f);
+                        depth = S.max_depth;
+                        has_ray = true;
+                    }
+                }
+                if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
+            }
         }
     }
 
@@ -415,14 +531,14 @@ uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t s
     return (uint32_t)n;
 }
 
-template <bool INST, bool COUNT>
+template <bool INST, bool COUNT, bool PIPELINED>
 static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, float* out, unsigned long long* d_counters,
                                         unsigned int* d_heads, int cu_count, hipStream_t stream) {
     // persistent grid: as many workgroups as the chip holds at once (never more than there are work items)
     static int blocks_per_cu = 0;  // per template instantiation
     if (blocks_per_cu == 0) {
         int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<INST, COUNT>, RENDER_BLOCK, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<INST, COUNT, PIPELINED>, RENDER_BLOCK, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = n > 0 ? n : 1;
         // experiment knob: fewer resident workgroups per CU (occupancy sensitivity)
@@ -435,7 +551,7 @@ static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, 
     const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;
     if (blocks > needed) blocks = needed;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((k_render<INST, COUNT>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
+    hipLaunchKernelGGL((k_render<INST, COUNT, PIPELINED>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
     return hipGetLastError();
 }
 
@@ -453,14 +569,20 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     G.node_share_64ths = tuning.node_share_64ths;
     G.leave_walk = tuning.leave_walk;
     G.leave_ready = tuning.leave_ready;
-    G.overlap_items = tuning.overlap_items;
     float* out = n_chunks > 1u ? d_partial : d_accum;
     const bool inst = S.has_instances != 0u;
     hipError_t e;
-    if (inst && count_visits) e = launch_render_variant<true, true>(S, G, out, d_counters, d_heads, cu_count, stream);
-    else if (inst) e = launch_render_variant<true, false>(S, G, out, d_counters, d_heads, cu_count, stream);
-    else if (count_visits) e = launch_render_variant<false, true>(S, G, out, d_counters, d_heads, cu_count, stream);
-    else e = launch_render_variant<false, false>(S, G, out, d_counters, d_heads, cu_count, stream);
+    const unsigned variant = (inst ? 4u : 0u) | (count_visits ? 2u : 0u) | (tuning.overlap_items != 0u ? 1u : 0u);
+    switch (variant) {
+        case 7u: e = launch_render_variant<true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 6u: e = launch_render_variant<true, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 5u: e = launch_render_variant<true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 4u: e = launch_render_variant<true, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 3u: e = launch_render_variant<false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 2u: e = launch_render_variant<false, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 1u: e = launch_render_variant<false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        default: e = launch_render_variant<false, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+    }
     if (e != hipSuccess || n_chunks <= 1u) return e;
     const uint32_t n_floats = width * height * 3u;
     hipLaunchKernelGGL(k_reduce_chunks, dim3((n_floats + 255u) / 256u), dim3(256), 0, stream, d_partial, n_floats, n_chunks, d_accum);

@@ -161,7 +161,6 @@ struct RenderGeom {
     uint32_t node_share_64ths;  // a node pass runs while at least this share (in 64ths) of the walking lanes descends
     uint32_t leave_walk;        // a trip's walk phase ends when at most this many lanes still walk ...
     uint32_t leave_ready;       // ... and at least this many lanes wait to shade (leave_walk 0: walk to the end)
-    uint32_t overlap_items;     // lanes move on to the wave's next item by themselves (1) or together (0)
 };
 
 // Per-lane traversal stack entries (LDS).  One inner-node step pushes at most one entry, so the stack never
