@@ -23,10 +23,11 @@ struct RenderTuning {
     uint32_t node_share_64ths = DEFAULT_NODE_SHARE_64THS;
     uint32_t refill_min = DEFAULT_REFILL_MIN;
     // Render kernel: a trip's walk phase ends with at most leave_walk lanes still walking if at least leave_ready
-    // lanes wait to shade; the stragglers finish their walk in the next trip.  Measured on MI355X (6 / 16): 10-11 %
-    // faster on the three large scenes, 1 % slower on the 968-triangle one, whose walks are short against a shading
-    // pass -- the library therefore switches it off (leave_walk = 0) for BVHs of fewer than 4096 nodes.
-    uint32_t leave_walk = 6u;
+    // lanes wait to shade; the stragglers finish their walk in the next trip.  Measured on MI355X: 10-20 % faster
+    // on the large scenes (optimum 12 on the 1M-triangle scene, 20 on the 10M-triangle ones, both within 2 % of
+    // each other), 1 % slower on the 968-triangle one, whose walks are short against a shading pass -- the
+    // library therefore switches it off (leave_walk = 0) for BVHs of fewer than 4096 nodes.
+    uint32_t leave_walk = 12u;
     uint32_t leave_ready = 16u;
     // Render kernel: the pipelined form (1: a wavefront holds two work items, and a lane that has finished its pixel
     // of the current one starts on the next one at once) or the item-at-a-time form (0).  Measured on MI355X: the
