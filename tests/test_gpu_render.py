@@ -127,9 +127,14 @@ def test_image_does_not_depend_on_wave_scheduling(rrt, monkeypatch, name):
     r.upload(helpers.SCENES[name](rrt))
     monkeypatch.setenv("RRT_CHUNKS", "2")
     monkeypatch.setenv("RRT_LEAVE_WALK", "0")
+    monkeypatch.setenv("RRT_OVERLAP_ITEMS", "0")  # one work item per wavefront at a time
     base, s0 = r.render(96, 54, 12)
+    monkeypatch.delenv("RRT_OVERLAP_ITEMS")
+    # RRT_OVERLAP_ITEMS=1: the pipelined form of the kernel, whose lanes move from one work item to the next by themselves
     for knobs in ({"RRT_LEAVE_WALK": "6"}, {"RRT_LEAVE_WALK": "40", "RRT_LEAVE_READY": "1"}, {"RRT_LEAVE_WALK": "63", "RRT_LEAVE_READY": "64"},
-                  {"RRT_LEAVE_WALK": "6", "RRT_NODE_SHARE": "0"}, {"RRT_LEAVE_WALK": "6", "RRT_NODE_SHARE": "64"}):
+                  {"RRT_LEAVE_WALK": "6", "RRT_NODE_SHARE": "0"}, {"RRT_LEAVE_WALK": "6", "RRT_NODE_SHARE": "64"},
+                  {"RRT_OVERLAP_ITEMS": "1"}, {"RRT_OVERLAP_ITEMS": "1", "RRT_LEAVE_WALK": "12"},
+                  {"RRT_OVERLAP_ITEMS": "1", "RRT_CHUNKS": "2", "RRT_LEAVE_WALK": "40", "RRT_LEAVE_READY": "1"}):
         for k, v in knobs.items():
             monkeypatch.setenv(k, v)
         img, st = r.render(96, 54, 12)
@@ -139,7 +144,7 @@ def test_image_does_not_depend_on_wave_scheduling(rrt, monkeypatch, name):
     r.close()
 
 
-def test_odd_sizes_and_single_sample(rrt, oracle):
+def test_odd_sizes_and_single_sample(rrt, oracle, monkeypatch):
     scene = helpers.scene_default(rrt)
     r = rrt.Renderer(seed=2)
     r.upload(scene)
@@ -149,6 +154,11 @@ def test_odd_sizes_and_single_sample(rrt, oracle):
         ref, rays = o.render(w, h, spp, seed=2)
         assert accum.shape == (h, w, 3) and st.samples == w * h * spp
         assert rel_l1(accum, ref) <= 2e-3 and abs(int(st.rays) - rays) <= 2
+        # the pipelined form of the kernel: same image bit for bit, partial tiles and single samples included
+        monkeypatch.setenv("RRT_OVERLAP_ITEMS", "1")
+        piped, st2 = r.render(w, h, spp)
+        monkeypatch.delenv("RRT_OVERLAP_ITEMS")
+        assert st2.rays == st.rays and np.array_equal(piped, accum)
     r.close()
 
 
