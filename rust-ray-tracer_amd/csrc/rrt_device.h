@@ -324,11 +324,14 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
 // Lanes that reach a leaf wait outside the loop; once fewer than `min_lanes` lanes are still descending the
 // pass ends for everybody, so that the waiting lanes get their primitive test instead of watching a handful
 // of lanes run node steps (min_lanes == 0: every lane descends until it is at a leaf).
+// In instanced scenes a lane that comes upon an instance (or upon the marker that ends one) changes its ray's space
+// right here and keeps descending: as a leaf step of its own the change would cost the wavefront a whole pass for
+// the few lanes that need it.  `o`, `d`: the world-space ray (only read when INST).
 template <bool INST, bool COUNT>
-__device__ __forceinline__ void trav_nodes(const SceneDev& S, float tmin, int* stack, int stride, Trav& T,
+__device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, int* stack, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes) {
-    const V3 ga = T.ga, gb = T.gb;
-    const uint32_t rx = T.rx, ry = T.ry, rz = T.rz;
+    V3 ga = T.ga, gb = T.gb;
+    uint32_t rx = T.rx, ry = T.ry, rz = T.rz;
     int cur = T.cur, sp = T.sp;
     while (cur >= 0) {
         // 32-bit byte offset from the uniform base: one shift, and the load takes the base from scalar registers
@@ -365,6 +368,34 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, float tmin, int* s
         } else {
             sp--;
             cur = stack[sp * stride];
+        }
+        if (INST) {
+            // kinds 3..6: instance, empty child, instance exit marker (the bottom-of-stack marker, kind 7, is not)
+            if ((uint32_t)cur - (REF_LEAF | (KIND_INST << 28)) < (4u << 28)) {
+                const uint32_t kind = ((uint32_t)cur >> 28) & 7u;
+                if (kind == KIND_INST) {
+                    const uint32_t first = (uint32_t)cur & REF_OFFSET_MASK;
+                    const InstRec in = S.insts[first];
+                    to_object_space(in, o, d, T.ro, T.rd);
+                    trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
+                    T.id_base = in.id_base;
+                    T.cur_inst = (int32_t)first;
+                    stack[sp * stride] = REF_INST_EXIT;
+                    sp++;
+                    cur = in.root;
+                } else {
+                    if (kind == KIND_INST_EXIT) {
+                        T.ro = o; T.rd = d;
+                        trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
+                        T.id_base = 0;
+                        T.cur_inst = -1;
+                    }
+                    sp--;
+                    cur = stack[sp * stride];
+                }
+                ga = T.ga; gb = T.gb;
+                rx = T.rx; ry = T.ry; rz = T.rz;
+            }
         }
         if ((uint32_t)__popcll(__ballot(cur >= 0)) < min_lanes) break;
     }
@@ -426,7 +457,7 @@ __device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin,
     Trav T;
     trav_begin<INST>(S, o, d, tmax, stack, T);
     while (T.cur != REF_DONE) {
-        trav_nodes<INST, COUNT>(S, tmin, stack, stride, T, cnt, 0u);  // 0: descend until this lane is at a leaf
+        trav_nodes<INST, COUNT>(S, o, d, tmin, stack, stride, T, cnt, 0u);  // 0: descend until this lane is at a leaf
         if (T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stack, stride, T, cnt);
     }
     best = T.best;

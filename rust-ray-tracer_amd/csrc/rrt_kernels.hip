@@ -132,7 +132,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
                             const uint32_t nodes0 = cnt.nodes;
-                            trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                            trav_nodes<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
                             uint32_t steps = cnt.nodes - nodes0;
                             for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                             if (lane == 0u) {
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                                 slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                             }
                         } else {
-                            trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                            trav_nodes<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
                         }
                     }
                     if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                        trav_nodes<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                         if (lane == 0u) {
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                             slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                         }
                     } else {
-                        trav_nodes<INST, COUNT>(S, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                        trav_nodes<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
                     }
                 }
                 if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, co
         const uint32_t n_walk = 64u - n_idle;
         const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
         const uint32_t share = (n_walk * node_share_64ths) >> 6;
-        if (n_desc == n_walk || n_desc >= share) trav_nodes<INST, COUNT>(S, tmin, stack, RENDER_BLOCK, T, cnt, share);
+        if (n_desc == n_walk || n_desc >= share) trav_nodes<INST, COUNT>(S, o, d, tmin, stack, RENDER_BLOCK, T, cnt, share);
         if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stack, RENDER_BLOCK, T, cnt);
     }
     if (COUNT) {
