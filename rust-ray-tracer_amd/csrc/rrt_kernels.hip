@@ -13,6 +13,7 @@
 // separate texts on purpose: written over shared helpers the pipelined form compiled to 3-20 % slower code
 // (register allocation at the 128-VGPR limit of four waves per SIMD).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 
 #include "rrt_device.h"
@@ -28,6 +29,15 @@ static constexpr uint32_t N_QUEUES = 8;   // workgroup ids congruent mod 8 are d
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
     return v;
+}
+
+// Tile number -> tile coordinates (bands of G.band_tiles tiles' width, row-major inside a band).
+__device__ __forceinline__ void tile_coords(const RenderGeom& G, uint32_t tile, uint32_t& tx, uint32_t& ty) {
+    const uint32_t band = min(tile / G.band_items, G.full_bands);
+    const uint32_t r = tile - band * G.band_items;
+    const uint32_t w = band < G.full_bands ? G.band_tiles : G.tiles_x - G.full_bands * G.band_tiles;
+    ty = r / w;
+    tx = band * G.band_tiles + r % w;
 }
 
 // First work item of queue q: the items are split into N_QUEUES contiguous ranges, i.e. contiguous image
@@ -83,7 +93,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
             const uint32_t work = draw();
             if (work == NO_WORK) break;  // every queue is empty: this wave is done
             const uint32_t tile = work / G.n_chunks, chunk = work % G.n_chunks;
-            const uint32_t tx = tile % G.tiles_x, ty = tile / G.tiles_x;
+            uint32_t tx, ty;
+            tile_coords(G, tile, tx, ty);
             const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
             const bool inside = x < width && y < height;
             // samples [first, first + spp) of this chunk, as absolute sample indices
@@ -203,8 +214,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                 const uint32_t tile = work / G.n_chunks;
                 chunk = work % G.n_chunks;
                 const uint32_t first = chunk * G.chunk_spp;  // samples [first, first + n_spp) as absolute sample indices
-                x0 = (tile % G.tiles_x) * 8u;
-                y0 = (tile / G.tiles_x) * 8u;
+                uint32_t tx, ty;
+                tile_coords(G, tile, tx, ty);
+                x0 = tx * 8u;
+                y0 = ty * 8u;
                 n_spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
                 first_sample = G.spp_offset + first;
             }
@@ -563,6 +576,9 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     G.width = width; G.height = height; G.spp = spp; G.spp_offset = spp_offset;
     G.tiles_x = (width + 7u) / 8u;
     G.n_tiles = G.tiles_x * ((height + 7u) / 8u);
+    G.band_tiles = tuning.band_tiles == 0u ? G.tiles_x : std::min(tuning.band_tiles, G.tiles_x);
+    G.band_items = G.band_tiles * ((height + 7u) / 8u);
+    G.full_bands = G.tiles_x / G.band_tiles;
     G.n_chunks = n_chunks;
     G.chunk_spp = (spp + n_chunks - 1u) / n_chunks;
     G.n_work = G.n_tiles * G.n_chunks;

@@ -157,6 +157,11 @@ struct SceneDev {
 struct RenderGeom {
     uint32_t width, height, spp, spp_offset;
     uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;
+    // Tiles are numbered band by band: vertical bands of `band_tiles` tiles' width, row by row inside a band, so that
+    // the items in flight at one time cover a compact block of the image instead of a strip of one tile's height.
+    uint32_t band_tiles;        // width of a full band in tiles
+    uint32_t band_items;        // tiles in a full band (band_tiles * rows of tiles)
+    uint32_t full_bands;        // bands of full width; one narrower band may follow
     uint32_t n_work;
     uint32_t node_share_64ths;  // a node pass runs while at least this share (in 64ths) of the walking lanes descends
     uint32_t leave_walk;        // a trip's walk phase ends when at most this many lanes still walk ...
