@@ -253,8 +253,24 @@ BuildResult build_bvh(std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes
         if (prims[i].kind == KIND_TRI) tri_order.push_back(prims[i].index);
     }
     const uint32_t used = bld.next_node.load();
+    // Nodes are emitted root first, the two children of a node next to each other, then the left subtree before the
+    // right one: the far child of a visit (popped later) shares a cache line with the near child more often than
+    // not, and a subtree is a contiguous run of nodes.
+    std::vector<uint32_t> order, remap(used, 0u), todo;
+    order.reserve(used);
+    order.push_back((uint32_t)top.ref);
+    todo.push_back((uint32_t)top.ref);
+    while (!todo.empty()) {
+        const uint32_t n = todo.back();
+        todo.pop_back();
+        const int32_t l = bld.local[n].left, r = bld.local[n].right;
+        if (l >= 0) { remap[(uint32_t)l] = (uint32_t)order.size(); order.push_back((uint32_t)l); }
+        if (r >= 0) { remap[(uint32_t)r] = (uint32_t)order.size(); order.push_back((uint32_t)r); }
+        if (r >= 0) todo.push_back((uint32_t)r);
+        if (l >= 0) todo.push_back((uint32_t)l);
+    }
     auto patch = [&](int32_t ref) -> int32_t {
-        if (ref >= 0) return ref + (int32_t)node_base;
+        if (ref >= 0) return (int32_t)(remap[(uint32_t)ref] + node_base);
         uint32_t u = (uint32_t)ref;
         uint32_t kind = (u >> 28) & 7u;
         if (kind == 5u) return ref;
@@ -263,14 +279,14 @@ BuildResult build_bvh(std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes
         if (kind == KIND_TRI) return (int32_t)make_leaf_ref(KIND_TRI, tri_base + tri_pos[pos], cnt);
         return (int32_t)make_leaf_ref(kind, prims[pos].index, 1u);
     };
-    nodes.reserve(nodes.size() + used);
-    for (uint32_t i = 0; i < used; ++i) {
-        BvhNode nd = bld.local[i];
+    nodes.reserve(nodes.size() + order.size());
+    for (uint32_t k = 0; k < (uint32_t)order.size(); ++k) {
+        BvhNode nd = bld.local[order[k]];
         nd.left = patch(nd.left);
         nd.right = patch(nd.right);
         nodes.push_back(nd);
     }
-    res.root = top.ref + (int32_t)node_base;
+    res.root = (int32_t)node_base;  // the root is emitted first
     res.depth = top.depth;
     for (int a = 0; a < 3; ++a) { res.root_min[a] = top.box.mn[a]; res.root_max[a] = top.box.mx[a]; }
     return res;
