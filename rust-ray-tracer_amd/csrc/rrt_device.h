@@ -290,7 +290,42 @@ struct Trav {
     V3 ro, rd;        // ray in the current space (instanced scenes only; otherwise the world ray is used)
     uint32_t id_base; // id offset of the instance being traversed
     int32_t cur_inst; // instance record being traversed, -1 at top level
+    // Short-stack form (template parameter K > 0 of the functions below): LDS holds the K most recent entries,
+    // logical positions [base, base + K) at slot (position mod K); older entries wait in the lane's `deep` array
+    // (private memory, kept outside this struct so that the struct stays in registers).
+    int base;
 };
+
+// Stack access.  K == 0: all STACK_DEPTH entries of a lane live in LDS.  K > 0 (a power of two): LDS holds a window
+// of K entries, which is what bounds the workgroups per CU; a push onto a full window first moves its oldest entry
+// to private memory, a pop from an empty window first brings one back.  Walks rarely go that deep (K = 16 against
+// typical depths of 10-14), so the extra cost is a compare per push and per pop.
+template <int K>
+__device__ __forceinline__ void stack_push(int* stack, int stride, int* deep, Trav& T, int& sp, int v) {
+    if (K > 0) {
+        if (sp - T.base == K) {
+            deep[T.base] = stack[(T.base & (K - 1)) * stride];
+            T.base++;
+        }
+        stack[(sp & (K - 1)) * stride] = v;
+    } else {
+        stack[sp * stride] = v;
+    }
+    sp++;
+}
+template <int K>
+__device__ __forceinline__ int stack_pop(int* stack, int stride, int* deep, Trav& T, int& sp) {
+    if (K > 0) {
+        if (sp == T.base) {  // the bottom marker is never popped twice, so base > 0 here
+            T.base--;
+            stack[(T.base & (K - 1)) * stride] = deep[T.base];
+        }
+        sp--;
+        return stack[(sp & (K - 1)) * stride];
+    }
+    sp--;
+    return stack[sp * stride];
+}
 
 __device__ __forceinline__ void trav_set_ray(Trav& T, V3 o, V3 d, const float* grid_origin, const float* grid_step) {
     const V3 inv = slab_reciprocal(d);
@@ -317,6 +352,7 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
     T.cur_inst = -1;
     stack[0] = REF_DONE;
     T.sp = 1;
+    T.base = 0;
     T.cur = S.root;
 }
 
@@ -327,9 +363,9 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
 // In instanced scenes a lane that comes upon an instance (or upon the marker that ends one) changes its ray's space
 // right here and keeps descending: as a leaf step of its own the change would cost the wavefront a whole pass for
 // the few lanes that need it.  `o`, `d`: the world-space ray (only read when INST).
-template <bool INST, bool COUNT>
+template <bool INST, bool COUNT, int K = 0>
 __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, int* stack, int stride, Trav& T,
-                                           TraceCounters& cnt, uint32_t min_lanes) {
+                                           TraceCounters& cnt, uint32_t min_lanes, int* deep = nullptr) {
     V3 ga = T.ga, gb = T.gb;
     uint32_t rx = T.rx, ry = T.ry, rz = T.rz;
     int cur = T.cur, sp = T.sp;
@@ -358,16 +394,14 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
         int left = (int)a.x, right = (int)a.y;
         if (hl && hr) {
             if (rn < ln) { int tmp = left; left = right; right = tmp; }
-            stack[sp * stride] = right;
-            sp++;
+            stack_push<K>(stack, stride, deep, T, sp, right);
             cur = left;
         } else if (hl) {
             cur = left;
         } else if (hr) {
             cur = right;
         } else {
-            sp--;
-            cur = stack[sp * stride];
+            cur = stack_pop<K>(stack, stride, deep, T, sp);
         }
         if (INST) {
             // kinds 3..6: instance, empty child, instance exit marker (the bottom-of-stack marker, kind 7, is not)
@@ -380,8 +414,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                     trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
                     T.id_base = in.id_base;
                     T.cur_inst = (int32_t)first;
-                    stack[sp * stride] = REF_INST_EXIT;
-                    sp++;
+                    stack_push<K>(stack, stride, deep, T, sp, REF_INST_EXIT);
                     cur = in.root;
                 } else {
                     if (kind == KIND_INST_EXIT) {
@@ -390,8 +423,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                         T.id_base = 0;
                         T.cur_inst = -1;
                     }
-                    sp--;
-                    cur = stack[sp * stride];
+                    cur = stack_pop<K>(stack, stride, deep, T, sp);
                 }
                 ga = T.ga; gb = T.gb;
                 rx = T.rx; ry = T.ry; rz = T.rz;
@@ -407,9 +439,9 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
 // leaf with more triangles stays current (reference advanced by one record), otherwise the next entry is popped.
 // One primitive per step keeps the cost of a pass the same for every lane, whatever its leaf holds.
 // Precondition: T.cur is negative and not REF_DONE.
-template <bool INST, bool COUNT>
+template <bool INST, bool COUNT, int K = 0>
 __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float tmin, int* stack, int stride, Trav& T,
-                                          TraceCounters& cnt) {
+                                          TraceCounters& cnt, int* deep = nullptr) {
     const uint32_t ref = (uint32_t)T.cur;
     const uint32_t kind = (ref >> 28) & 7u;
     const uint32_t first = ref & REF_OFFSET_MASK;
@@ -436,8 +468,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
         T.id_base = in.id_base;
         T.cur_inst = (int32_t)first;
-        stack[T.sp * stride] = REF_INST_EXIT;
-        T.sp++;
+        stack_push<K>(stack, stride, deep, T, T.sp, REF_INST_EXIT);
         T.cur = in.root;
         return;
     } else if (INST && kind == KIND_INST_EXIT) {
@@ -446,8 +477,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         T.id_base = 0;
         T.cur_inst = -1;
     }
-    T.sp--;
-    T.cur = stack[T.sp * stride];
+    T.cur = stack_pop<K>(stack, stride, deep, T, T.sp);
 }
 
 // Complete walk of one ray (used by the ray-batch kernel): the same passes as the render kernel, run to the end.

@@ -24,6 +24,7 @@ namespace rrt {
 static constexpr int WAVE = 64;
 static constexpr int RENDER_BLOCK = 256;  // 4 independent wavefronts per workgroup
 static constexpr uint32_t TRACE_BLOCK = 512;  // ray indices a wavefront of the streaming kernel draws at a time
+static constexpr int RENDER_STACK = 16;   // traversal stack entries per lane the render kernel keeps in LDS (short stack)
 static constexpr uint32_t N_QUEUES = 8;   // workgroup ids congruent mod 8 are dealt to one XCD and share its L2
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -47,13 +48,17 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 }
 
 template <bool INST, bool COUNT, bool PIPELINED>
-__global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+__global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
-    __shared__ int s_stack[STACK_DEPTH * RENDER_BLOCK];
+    // Flat scenes keep RENDER_STACK entries per lane in LDS (six workgroups per CU); instanced scenes, whose kernel
+    // needs more registers than six or five waves per SIMD leave it, keep the whole stack there (four per CU).
+    constexpr int K = INST ? 0 : RENDER_STACK;
+    __shared__ int s_stack[(INST ? STACK_DEPTH : RENDER_STACK) * RENDER_BLOCK];
     __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 16];  // per wavefront: the records of its two work items
     const uint32_t lane = threadIdx.x & 63u;
     int* stack = s_stack + threadIdx.x;
+    int deep[STACK_DEPTH - RENDER_STACK];  // stack entries below the LDS window (private memory; rarely touched)
     const uint32_t width = G.width, height = G.height;
     const V3 bg = v3(S.background[0], S.background[1], S.background[2]);
 
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
                             const uint32_t nodes0 = cnt.nodes;
-                            trav_nodes<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                            trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share, deep);
                             uint32_t steps = cnt.nodes - nodes0;
                             for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                             if (lane == 0u) {
@@ -151,10 +156,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                                 slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                             }
                         } else {
-                            trav_nodes<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                            trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share, deep);
                         }
                     }
-                    if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
+                    if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, deep);
                 }
                 // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
                 if (has_ray && T.cur == REF_DONE) {
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                        trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share, deep);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                         if (lane == 0u) {
@@ -283,10 +288,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_render(SceneDev S, RenderGe
                             slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                         }
                     } else {
-                        trav_nodes<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share);
+                        trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share, deep);
                     }
                 }
-                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt);
+                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, deep);
             }
 
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
