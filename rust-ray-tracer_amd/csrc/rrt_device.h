@@ -290,40 +290,22 @@ struct Trav {
     V3 ro, rd;        // ray in the current space (instanced scenes only; otherwise the world ray is used)
     uint32_t id_base; // id offset of the instance being traversed
     int32_t cur_inst; // instance record being traversed, -1 at top level
-    // Short-stack form (template parameter K > 0 of the functions below): LDS holds the K most recent entries,
-    // logical positions [base, base + K) at slot (position mod K); older entries wait in the lane's `deep` array
-    // (private memory, kept outside this struct so that the struct stays in registers).
-    int base;
 };
 
-// Stack access.  K == 0: all STACK_DEPTH entries of a lane live in LDS.  K > 0 (a power of two): LDS holds a window
-// of K entries, which is what bounds the workgroups per CU; a push onto a full window first moves its oldest entry
-// to private memory, a pop from an empty window first brings one back.  Walks rarely go that deep (K = 16 against
-// typical depths of 10-14), so the extra cost is a compare per push and per pop.
+// Stack access.  K == 0: all STACK_DEPTH entries of a lane live in LDS.  K > 0: LDS holds entries 0 .. K-1, which is
+// what bounds the workgroups per CU, and the entries above them live in the lane's `deep` array (private memory).
+// Walks rarely go that deep (K = 16 against typical depths of 10-14), so the extra cost is a compare per push and
+// per pop.
 template <int K>
-__device__ __forceinline__ void stack_push(int* stack, int stride, int* deep, Trav& T, int& sp, int v) {
-    if (K > 0) {
-        if (sp - T.base == K) {
-            deep[T.base] = stack[(T.base & (K - 1)) * stride];
-            T.base++;
-        }
-        stack[(sp & (K - 1)) * stride] = v;
-    } else {
-        stack[sp * stride] = v;
-    }
+__device__ __forceinline__ void stack_push(int* stack, int stride, int* deep, int& sp, int v) {
+    if (K > 0 && sp >= K) deep[sp - K] = v;
+    else stack[sp * stride] = v;
     sp++;
 }
 template <int K>
-__device__ __forceinline__ int stack_pop(int* stack, int stride, int* deep, Trav& T, int& sp) {
-    if (K > 0) {
-        if (sp == T.base) {  // the bottom marker is never popped twice, so base > 0 here
-            T.base--;
-            stack[(T.base & (K - 1)) * stride] = deep[T.base];
-        }
-        sp--;
-        return stack[(sp & (K - 1)) * stride];
-    }
+__device__ __forceinline__ int stack_pop(int* stack, int stride, int* deep, int& sp) {
     sp--;
+    if (K > 0 && sp >= K) return deep[sp - K];
     return stack[sp * stride];
 }
 
@@ -352,7 +334,6 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
     T.cur_inst = -1;
     stack[0] = REF_DONE;
     T.sp = 1;
-    T.base = 0;
     T.cur = S.root;
 }
 
@@ -394,14 +375,14 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
         int left = (int)a.x, right = (int)a.y;
         if (hl && hr) {
             if (rn < ln) { int tmp = left; left = right; right = tmp; }
-            stack_push<K>(stack, stride, deep, T, sp, right);
+            stack_push<K>(stack, stride, deep, sp, right);
             cur = left;
         } else if (hl) {
             cur = left;
         } else if (hr) {
             cur = right;
         } else {
-            cur = stack_pop<K>(stack, stride, deep, T, sp);
+            cur = stack_pop<K>(stack, stride, deep, sp);
         }
         if (INST) {
             // kinds 3..6: instance, empty child, instance exit marker (the bottom-of-stack marker, kind 7, is not)
@@ -414,7 +395,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                     trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
                     T.id_base = in.id_base;
                     T.cur_inst = (int32_t)first;
-                    stack_push<K>(stack, stride, deep, T, sp, REF_INST_EXIT);
+                    stack_push<K>(stack, stride, deep, sp, REF_INST_EXIT);
                     cur = in.root;
                 } else {
                     if (kind == KIND_INST_EXIT) {
@@ -423,7 +404,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                         T.id_base = 0;
                         T.cur_inst = -1;
                     }
-                    cur = stack_pop<K>(stack, stride, deep, T, sp);
+                    cur = stack_pop<K>(stack, stride, deep, sp);
                 }
                 ga = T.ga; gb = T.gb;
                 rx = T.rx; ry = T.ry; rz = T.rz;
@@ -468,7 +449,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
         T.id_base = in.id_base;
         T.cur_inst = (int32_t)first;
-        stack_push<K>(stack, stride, deep, T, T.sp, REF_INST_EXIT);
+        stack_push<K>(stack, stride, deep, T.sp, REF_INST_EXIT);
         T.cur = in.root;
         return;
     } else if (INST && kind == KIND_INST_EXIT) {
@@ -477,7 +458,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         T.id_base = 0;
         T.cur_inst = -1;
     }
-    T.cur = stack_pop<K>(stack, stride, deep, T, T.sp);
+    T.cur = stack_pop<K>(stack, stride, deep, T.sp);
 }
 
 // Complete walk of one ray (used by the ray-batch kernel): the same passes as the render kernel, run to the end.
