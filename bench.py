@@ -115,10 +115,14 @@ def measured_pmc(config: int, width: int, height: int, spp: int):
     return row
 
 
-# Issue time of one wave-instruction on one SIMD for the classes the traversal loop is made of, measured with
-# tools/valu_peak.hip at 4 waves per SIMD (profiles/round1_valu_issue_rate_mi355x.txt).  v_fma_f32 is the fastest class.
-VALU_NS_FMA = 3.06 / 2.4
-VALU_NS_SELECT_CLASS = 4.3 / 2.4  # min/max/min3/max3, sub-dword converts, compare + select
+# Issue cost in cycles of one wave-instruction on one SIMD, by instruction class, measured with tools/valu_peak.hip
+# (profiles/round1_valu_issue_rate_mi355x.txt): plain add/mul/logic/move, v_fma_f32, and the class of min/max/min3/max3,
+# sub-dword converts, bit-field and select forms.  VALU_MIX_CYCLES prices the render kernel's own mix: per ray about
+# 35 instructions of node steps (12 fma, 26 of the slow class, 9 plain per step: 3.6 cycles each), 17 of triangle tests
+# (mostly plain mul/add: 2.8) and 20 of shading and bookkeeping (3.0).
+GPU_GHZ = 2.4
+VALU_CLASS_CYCLES = {"add_mul_logic": 2.5, "fma": 3.06, "minmax_convert_select": 4.3}
+VALU_MIX_CYCLES = 3.3
 
 
 def main():
@@ -255,10 +259,13 @@ def main():
         if pmc and "sq_insts_valu" in pmc:
             per_simd = pmc["sq_insts_valu"] / pmc["simds"]
             # the kernel is bound by vector-ALU issue, not by HBM: share of the launch a SIMD spends issuing VALU
-            # instructions, priced at the fastest class (lower bound) and at the class most of the loop belongs to
+            # instructions, priced at the fma rate and at the kernel's own instruction mix
+            cycles_per_inst = k_ms * 1e-3 * GPU_GHZ * 1e9 / per_simd  # SIMD cycles of the launch per VALU instruction issued
             roof["valu"] = {"insts_per_ray": pmc["sq_insts_valu"] / rays_per_step,
-                            "issue_frac_at_fma_rate": per_simd * VALU_NS_FMA * 1e-6 / k_ms,
-                            "issue_frac_at_select_rate": per_simd * VALU_NS_SELECT_CLASS * 1e-6 / k_ms,
+                            "simd_cycles_per_inst": cycles_per_inst,
+                            "class_cycles": VALU_CLASS_CYCLES,
+                            "issue_frac_at_fma_rate": VALU_CLASS_CYCLES["fma"] / cycles_per_inst,
+                            "issue_frac_at_kernel_mix": VALU_MIX_CYCLES / cycles_per_inst,
                             "source": "profiles/pmc_per_launch.json (rocprofv3 --pmc SQ_INSTS_VALU), tools/valu_peak.hip"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene, width, height, spp, args.seed)
