@@ -238,8 +238,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
         // per lane: `stage` = which of the two items it is on (0: current, 1: next, 2: done with both), + 4 once it
         // has taken its pixel of that item; then its place in the item
         uint32_t stage = 0u;
-        uint32_t x = 0, y = 0, pixel = 0, item_chunk = 0, item_spp = 0, item_first = 0;
-        uint32_t s = 0;          // sample counter within the item
+        // (kept small: the kernel runs at the register budget of six waves per SIMD)
+        uint32_t xy = 0;           // the lane's pixel, x | y << 16
+        uint32_t next_sample = 0;  // absolute index of the next sample to start
+        uint32_t left = 0;         // samples of the item not yet finished
         bool has_ray = false;    // a ray is in flight (being walked, or waiting to be shaded)
         V3 sum = v3(0.f, 0.f, 0.f);
         V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), beta = v3(0.f, 0.f, 0.f), radiance = v3(0.f, 0.f, 0.f);
@@ -316,13 +318,16 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                     bool start = shade_now;
                     if (shade_now) {
                         sum = sum + radiance;  // main.rs:95
-                        s++;
-                        if (s >= item_spp) {  // this lane's part of the item is complete: one 12-byte store
-                            float* px = out + 3ull * ((size_t)item_chunk * width * height + pixel);
+                        left--;
+                        if (left == 0u) {  // this lane's part of the item is complete: one 12-byte store
+                            const uint32_t on = stage & 3u;
+                            const uint32_t chunk = items[(on == 0u ? cur_slot : cur_slot ^ 1u) * 8u + 2u];
+                            const uint32_t pixel = (xy >> 16) * width + (xy & 0xFFFFu);
+                            float* px = out + 3ull * ((size_t)chunk * width * height + pixel);
                             px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
                             has_ray = false;
                             start = false;
-                            stage = (stage & 3u) + 1u;
+                            stage = on + 1u;
                             take = stage == 1u;
                         }
                     }
@@ -331,11 +336,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                         const uint32_t px_x = rec[0] + (lane & 7u), px_y = rec[1] + (lane >> 3);
                         const uint32_t n_spp = rec[3];
                         if (px_x < width && px_y < height && n_spp != 0u) {
-                            x = px_x; y = px_y; pixel = px_y * width + px_x;
-                            item_chunk = rec[2];
-                            item_spp = n_spp;
-                            item_first = rec[4];
-                            s = 0u;
+                            xy = px_x | (px_y << 16);
+                            left = n_spp;
+                            next_sample = rec[4];
                             sum = v3(0.f, 0.f, 0.f);
                             stage += 4u;
                             start = true;
@@ -344,7 +347,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                         }
                     }
                     if (start) {
-                        rng = rng_init(S.seed, pixel, item_first + s);
+                        const uint32_t x = xy & 0xFFFFu, y = xy >> 16;
+                        rng = rng_init(S.seed, y * width + x, next_sample);
+                        next_sample++;
                         const float u = (float)x + rng_f32(rng);  // main.rs:92-93
                         const float v = (float)y + rng_f32(rng);
                         rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
@@ -593,7 +598,9 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     float* out = n_chunks > 1u ? d_partial : d_accum;
     const bool inst = S.has_instances != 0u;
     hipError_t e;
-    const unsigned variant = (inst ? 4u : 0u) | (count_visits ? 2u : 0u) | (tuning.overlap_items != 0u ? 1u : 0u);
+    // the pipelined form packs a lane's pixel coordinates into 16 bits each
+    const bool pipelined = tuning.overlap_items != 0u && width < 65536u && height < 65536u;
+    const unsigned variant = (inst ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
     switch (variant) {
         case 7u: e = launch_render_variant<true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
         case 6u: e = launch_render_variant<true, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
