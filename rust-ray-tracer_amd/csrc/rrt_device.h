@@ -286,7 +286,6 @@ struct Trav {
     int sp;           // stack entries in use
     Best best;
     V3 ga, gb;        // slab test constants of the ray on the current BVH's grid: plane q lies at t = q * ga + gb
-    uint32_t rx, ry, rz;  // 16 where the ray runs against the axis (ga < 0), else 0: rotate count of a node's plane pair
     V3 ro, rd;        // ray in the current space (instanced scenes only; otherwise the world ray is used)
     uint32_t id_base; // id offset of the instance being traversed
     int32_t cur_inst; // instance record being traversed, -1 at top level
@@ -313,9 +312,6 @@ __device__ __forceinline__ void trav_set_ray(Trav& T, V3 o, V3 d, const float* g
     const V3 inv = slab_reciprocal(d);
     T.ga = v3(grid_step[0] * inv.x, grid_step[1] * inv.y, grid_step[2] * inv.z);
     T.gb = v3((grid_origin[0] - o.x) * inv.x, (grid_origin[1] - o.y) * inv.y, (grid_origin[2] - o.z) * inv.z);
-    T.rx = (__float_as_uint(inv.x) >> 31) << 4;
-    T.ry = (__float_as_uint(inv.y) >> 31) << 4;
-    T.rz = (__float_as_uint(inv.z) >> 31) << 4;
 }
 
 // (entry plane distance, exit plane distance) of one axis of a child box: `w` holds (min index | max index << 16)
@@ -348,7 +344,9 @@ template <bool INST, bool COUNT, int K = 0>
 __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, int* stack, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes, int* deep = nullptr) {
     V3 ga = T.ga, gb = T.gb;
-    uint32_t rx = T.rx, ry = T.ry, rz = T.rz;
+    // rotate count of a node's plane pair: 16 where the ray runs against the axis (the sign of ga, the grid step
+    // being positive), else 0
+    uint32_t rx = (__float_as_uint(ga.x) >> 31) << 4, ry = (__float_as_uint(ga.y) >> 31) << 4, rz = (__float_as_uint(ga.z) >> 31) << 4;
     int cur = T.cur, sp = T.sp;
     while (cur >= 0) {
         // 32-bit byte offset from the uniform base: one shift, and the load takes the base from scalar registers
@@ -407,7 +405,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                     cur = stack_pop<K>(stack, stride, deep, sp);
                 }
                 ga = T.ga; gb = T.gb;
-                rx = T.rx; ry = T.ry; rz = T.rz;
+                rx = (__float_as_uint(ga.x) >> 31) << 4; ry = (__float_as_uint(ga.y) >> 31) << 4; rz = (__float_as_uint(ga.z) >> 31) << 4;
             }
         }
         if ((uint32_t)__popcll(__ballot(cur >= 0)) < min_lanes) break;
