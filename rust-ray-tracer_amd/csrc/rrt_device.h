@@ -291,21 +291,29 @@ struct Trav {
     int32_t cur_inst; // instance record being traversed, -1 at top level
 };
 
+// The traversal stack is addressed as LDS (address space 3) throughout, so that every access is a ds_read / ds_write
+// and never a flat access through a generic pointer.
+typedef __attribute__((address_space(3))) int lds_int;
+
 // Stack access.  K == 0: all STACK_DEPTH entries of a lane live in LDS.  K > 0: LDS holds entries 0 .. K-1, which is
 // what bounds the workgroups per CU, and the entries above them live in the lane's `deep` array (private memory).
 // Walks rarely go that deep (K = 16 against typical depths of 10-14), so the extra cost is a compare per push and
 // per pop.
 template <int K>
-__device__ __forceinline__ void stack_push(int* stack, int stride, int* deep, int& sp, int v) {
+__device__ __forceinline__ void stack_push(lds_int* stack, int stride, int* deep, int& sp, int v) {
     if (K > 0 && sp >= K) deep[sp - K] = v;
     else stack[sp * stride] = v;
     sp++;
 }
 template <int K>
-__device__ __forceinline__ int stack_pop(int* stack, int stride, int* deep, int& sp) {
+__device__ __forceinline__ int stack_pop(lds_int* stack, int stride, int* deep, int& sp) {
     sp--;
-    if (K > 0 && sp >= K) return deep[sp - K];
-    return stack[sp * stride];
+    if (K == 0) return stack[sp * stride];
+    // the LDS read is unconditional (entry K-1 for a deep index): written as an either-or, the two loads are merged
+    // into one flat load through a selected generic address
+    int v = stack[(sp < K ? sp : K - 1) * stride];
+    if (sp >= K) v = deep[sp - K];
+    return v;
 }
 
 __device__ __forceinline__ void trav_set_ray(Trav& T, V3 o, V3 d, const float* grid_origin, const float* grid_step) {
@@ -322,7 +330,7 @@ __device__ __forceinline__ void slab_pair(uint32_t w, uint32_t rot, float a, flo
 }
 
 template <bool INST>
-__device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, int* stack, Trav& T) {
+__device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, lds_int* stack, Trav& T) {
     T.best.t = tmax; T.best.id = 0xFFFFFFFFu; T.best.u = 0.f; T.best.v = 0.f; T.best.what = 0u; T.best.inst = -1;
     trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
     if (INST) { T.ro = o; T.rd = d; }
@@ -341,7 +349,7 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
 // right here and keeps descending: as a leaf step of its own the change would cost the wavefront a whole pass for
 // the few lanes that need it.  `o`, `d`: the world-space ray (only read when INST).
 template <bool INST, bool COUNT, int K = 0>
-__device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, int* stack, int stride, Trav& T,
+__device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, lds_int* stack, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes, int* deep = nullptr) {
     V3 ga = T.ga, gb = T.gb;
     // rotate count of a node's plane pair: 16 where the ray runs against the axis (the sign of ga, the grid step
@@ -419,7 +427,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
 // One primitive per step keeps the cost of a pass the same for every lane, whatever its leaf holds.
 // Precondition: T.cur is negative and not REF_DONE.
 template <bool INST, bool COUNT, int K = 0>
-__device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float tmin, int* stack, int stride, Trav& T,
+__device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float tmin, lds_int* stack, int stride, Trav& T,
                                           TraceCounters& cnt, int* deep = nullptr) {
     const uint32_t ref = (uint32_t)T.cur;
     const uint32_t kind = (ref >> 28) & 7u;
@@ -461,7 +469,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
 
 // Complete walk of one ray (used by the ray-batch kernel): the same passes as the render kernel, run to the end.
 template <bool INST, bool COUNT>
-__device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin, float tmax, int* stack, int stride,
+__device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin, float tmax, lds_int* stack, int stride,
                                       Best& best, TraceCounters& cnt) {
     Trav T;
     trav_begin<INST>(S, o, d, tmax, stack, T);

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
     __shared__ int s_stack[(INST ? STACK_DEPTH : RENDER_STACK) * RENDER_BLOCK];
     __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 16];  // per wavefront: the records of its two work items
     const uint32_t lane = threadIdx.x & 63u;
-    int* stack = s_stack + threadIdx.x;
+    lds_int* stack = (lds_int*)(s_stack + threadIdx.x);
     int deep[STACK_DEPTH - RENDER_STACK];  // stack entries below the LDS window (private memory; rarely touched)
     const uint32_t width = G.width, height = G.height;
     const V3 bg = v3(S.background[0], S.background[1], S.background[2]);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* _
     const V3 d = v3(r.direction[0], r.direction[1], r.direction[2]);
     Best best;
     TraceCounters cnt = {0u, 0u, 0u, 0u, 0u};
-    trace<INST, false>(S, o, d, tmin, tmax, s_stack + threadIdx.x, WAVE, best, cnt);
+    trace<INST, false>(S, o, d, tmin, tmax, (lds_int*)(s_stack + threadIdx.x), WAVE, best, cnt);
     out[i] = hit_record(S, best, o, d);
 }
 
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, co
                                                                   uint32_t node_share_64ths,
                                                                   unsigned long long* __restrict__ counters) {
     __shared__ int s_stack[STACK_DEPTH * RENDER_BLOCK];
-    int* stack = s_stack + threadIdx.x;
+    lds_int* stack = (lds_int*)(s_stack + threadIdx.x);
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t mine = 0xFFFFFFFFu;  // index of the ray this lane is walking (or has walked and not yet written)
     V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
