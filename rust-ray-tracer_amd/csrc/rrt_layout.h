@@ -65,13 +65,14 @@ struct alignas(16) QNode {
 };
 static_assert(sizeof(QNode) == 32, "QNode must be 32 bytes");
 
-// Plane indices of one child box [mn, mx] on grid g, rounded outwards by one extra plane: the stored box contains
-// the given one.  Used by the host builder and by the on-device builder alike.
+// Plane indices of one child box [mn, mx] on grid g, rounded outwards to the nearest plane: the stored box contains
+// the given one (the quotient is formed in double precision; its rounding error, 1e-16 of a plane index, is far
+// inside the margin every box already carries).  Used by the host builder and by the on-device builder alike.
 RRT_HD static inline void quantize_box(const Grid& g, const float* mn, const float* mx, uint32_t* out) {
     for (int a = 0; a < 3; ++a) {
         const double o = g.origin[a], s = g.step[a];
-        double qlo = floor(((double)mn[a] - o) / s) - 1.0;
-        double qhi = ceil(((double)mx[a] - o) / s) + 1.0;
+        double qlo = floor(((double)mn[a] - o) / s);
+        double qhi = ceil(((double)mx[a] - o) / s);
         if (!(qlo >= 0.0)) qlo = 0.0;          // also catches the NaN of an empty slot's sentinel box
         if (!(qhi <= 65535.0)) qhi = 65535.0;
         if (qlo > 65535.0) qlo = 65535.0;
