@@ -249,6 +249,13 @@ rrt_status rrt_tonemap(rrt_ctx* ctx, const float* accum, uint32_t width, uint32_
 rrt_status rrt_tonemap_device(rrt_ctx* ctx, const float* d_accum, uint32_t width, uint32_t height,
                               uint32_t spp_total, uint8_t* d_rgb8, void* stream);
 
+/* ---- arithmetic self-test ----  no counterpart in the reference.  The kernels form 1/x and sqrt(x) in the primitive
+ * tests and the light pdf (reference src/geometry/triangle.rs:46, src/geometry/sphere.rs:61,107-108) with a short
+ * instruction sequence that must round exactly like the IEEE operations the reference's f32 arithmetic uses.  This
+ * call runs that sequence and the IEEE operation over ALL 2^32 float bit patterns on the ctx's GPU and reports the
+ * number of patterns on which they differ in any bit (both must be 0).                                             */
+rrt_status rrt_selftest_arith(rrt_ctx* ctx, uint64_t* recip_mismatches, uint64_t* sqrt_mismatches);
+
 /* ---- front end helpers (host only; not accelerated) ---- */
 
 /* Scene construction from glTF -- replaces `Scene::from_gltf_file` (reference src/gltf.rs:314-351).

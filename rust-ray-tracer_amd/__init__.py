@@ -142,7 +142,7 @@ ABI_SYMBOLS = [
     "rrt_abi_version", "rrt_create", "rrt_destroy", "rrt_last_error", "rrt_scene_upload", "rrt_scene_get_info",
     "rrt_scene_check",
     "rrt_intersect", "rrt_intersect_device", "rrt_render", "rrt_render_device", "rrt_render_stats", "rrt_tonemap",
-    "rrt_tonemap_device", "rrt_gltf_load", "rrt_scene_free", "rrt_png_write",
+    "rrt_tonemap_device", "rrt_selftest_arith", "rrt_gltf_load", "rrt_scene_free", "rrt_png_write",
 ]
 
 _lib = None
@@ -173,6 +173,7 @@ def load_library() -> C.CDLL:
     lib.rrt_render_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.rrt_tonemap.argtypes = [vp, vp, u32, u32, u32, vp]
     lib.rrt_tonemap_device.argtypes = [vp, vp, u32, u32, u32, vp, vp]
+    lib.rrt_selftest_arith.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.rrt_gltf_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(GltfOptions), C.POINTER(C.POINTER(SceneDescPOD))]
     lib.rrt_scene_free.argtypes = [C.POINTER(SceneDescPOD)]
     lib.rrt_scene_free.restype = None
@@ -516,6 +517,13 @@ class Renderer:
 
     def tonemap_device(self, d_accum: int, width: int, height: int, spp_total: int, d_rgb8: int, stream: int = 0):
         _check(self.lib.rrt_tonemap_device(self.ctx, d_accum, width, height, spp_total, d_rgb8, stream), self.ctx)
+
+    def selftest_arith(self):
+        """(reciprocal mismatches, square-root mismatches) of the kernels' short forms against the IEEE operations
+        over all 2^32 float bit patterns."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self.lib.rrt_selftest_arith(self.ctx, C.byref(a), C.byref(b)), self.ctx)
+        return a.value, b.value
 
 
 def png_write(path: str, rgb8: np.ndarray):

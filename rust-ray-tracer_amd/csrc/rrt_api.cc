@@ -449,4 +449,22 @@ rrt_status rrt_tonemap(rrt_ctx* c, const float* accum, uint32_t width, uint32_t 
     return st;
 }
 
+rrt_status rrt_selftest_arith(rrt_ctx* c, uint64_t* recip_mismatches, uint64_t* sqrt_mismatches) {
+    if (!c) return set_err(nullptr, RRT_ERR_INVALID, "rrt_selftest_arith: ctx is NULL");
+    if (!recip_mismatches || !sqrt_mismatches) return set_err(c, RRT_ERR_INVALID, "rrt_selftest_arith: NULL output");
+    RRT_HIP(c, hipSetDevice(c->cfg.device));
+    unsigned long long* d_bad = nullptr;
+    unsigned long long bad[2] = {0ull, 0ull};
+    hipError_t e = hipMalloc((void**)&d_bad, sizeof bad);
+    if (e == hipSuccess) e = hipMemset(d_bad, 0, sizeof bad);
+    if (e == hipSuccess) e = launch_check_arith(d_bad, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
+    if (d_bad) (void)hipFree(d_bad);
+    if (e != hipSuccess) return hip_fail(c, e, "rrt_selftest_arith");
+    *recip_mismatches = bad[0];
+    *sqrt_mismatches = bad[1];
+    return RRT_OK;
+}
+
 }  // extern "C"

@@ -28,7 +28,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 __device__ __forceinline__ float length_squared(V3 a) { return dot(a, a); }
-__device__ __forceinline__ V3 normalize(V3 a) { return a / sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a);  // defined after sqrt_rn
 __device__ __forceinline__ float comp(V3 a, uint32_t axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
 #define RRT_PI 3.14159274101257324f  // std::f32::consts::PI
 #define RRT_INV_PI 0.318309886183790672f
@@ -43,6 +43,32 @@ __device__ __forceinline__ float signum(float x) { return x != x ? x : copysignf
 __device__ __forceinline__ float rcp_1ulp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq_1ulp(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ V3 unit(V3 a) { return a * rsq_1ulp(dot(a, a)); }  // glam normalize, to 1-2 ulp
+
+// Correctly rounded 1/x and sqrt(x) in short form.  The compiler's IEEE sequences take 11 and 16 instructions (range
+// scaling, two correction steps, fix-ups).  For operands away from the ends of the exponent range one Newton step in
+// fused arithmetic on the hardware estimate (1 ulp) already gives the correctly rounded result: k_check_arith in
+// rrt_kernels.hip compares both functions with the IEEE operations for EVERY one of the 2^32 float bit patterns on
+// the device (tests/test_gpu_arith.py).  Operands outside the range the short form is exact on (zero, denormals,
+// negative numbers, infinities, NaN, the last binades) take the IEEE path, so results are bit-identical everywhere.
+__device__ __forceinline__ float recip_rn(float x) {
+    // positive normal x below 2^126 (above it the quotient is denormal)
+    if (__float_as_uint(x) - 0x00800000u < 0x7E800000u - 0x00800000u) {
+        const float r = __builtin_amdgcn_rcpf(x);
+        return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    }
+    return 1.0f / x;
+}
+__device__ __forceinline__ float sqrt_rn(float x) {
+    // finite x of at least 2^-100 (below it the residual of the Newton step is denormal)
+    if (__float_as_uint(x) - 0x0D800000u < 0x7F800000u - 0x0D800000u) {
+        const float y = __builtin_amdgcn_rsqf(x);
+        const float s = x * y;
+        return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * y, s);
+    }
+    return sqrtf(x);
+}
+
+__device__ __forceinline__ V3 normalize(V3 a) { return a / sqrt_rn(dot(a, a)); }
 
 // (sin, cos) of 2*pi*turn for turn in [0, 1): the nearest quarter turn is removed exactly, then the Cephes
 // single-precision polynomials on [-pi/4, pi/4] (about 1 ulp), then the quadrant is put back.
@@ -151,7 +177,7 @@ __device__ __forceinline__ void test_triangle(const TriRec* __restrict__ tris, u
     const V3 pvec = cross(d, e2);
     const float det = dot(e1, pvec);
     if (det > 1e-5f) {
-        const float inv_det = 1.0f / det;
+        const float inv_det = recip_rn(det);  // == 1.0f / det
         const V3 tvec = o - v0;
         const float u = dot(tvec, pvec) * inv_det;
         if (u >= 0.0f && u <= 1.0f) {
@@ -179,7 +205,7 @@ __device__ __forceinline__ float sphere_root(V3 c, float radius, V3 o, V3 d, flo
     const float cc = length_squared(oc) - radius * radius;
     const float disc = b * b - a * cc;
     if (disc > 0.0f) {
-        const float sq = sqrtf(disc);
+        const float sq = sqrt_rn(disc);
         float root = (-b - sq) / a;
         if (tmin <= root && root <= tmax) return root;
         root = (-b + sq) / a;
@@ -559,9 +585,9 @@ __device__ __forceinline__ float lights_pdf(const SceneDev& S, V3 origin, V3 v) 
             const V3 c = v3(L.p0, L.p1, L.p2);
             const float root = sphere_root(c, L.p3, origin, v, 0.0001f, __builtin_inff());
             if (root == root) {
-                const float cos_theta_max = sqrtf(1.0f - L.p3 * L.p3 / length_squared(c - origin));
+                const float cos_theta_max = sqrt_rn(1.0f - L.p3 * L.p3 / length_squared(c - origin));
                 const float solid_angle = 2.0f * RRT_PI * (1.0f - cos_theta_max);
-                pdf = 1.0f / solid_angle;
+                pdf = recip_rn(solid_angle);
             }
         } else if (L.type == 1u) {
             float t, uu, vv;
@@ -569,7 +595,7 @@ __device__ __forceinline__ float lights_pdf(const SceneDev& S, V3 origin, V3 v) 
                 const float area = (L.p1 - L.p0) * (L.p3 - L.p2);
                 const float dist2 = t * t * length_squared(v);
                 const V3 n = v3(0.0f, signum(origin.y - L.p4), 0.0f);
-                const float cosine = fabsf(dot(v, n)) / sqrtf(length_squared(v));
+                const float cosine = fabsf(dot(v, n)) / sqrt_rn(length_squared(v));
                 pdf = dist2 / (cosine * area);
             }
         }
@@ -582,8 +608,8 @@ __device__ __forceinline__ float lights_pdf(const SceneDev& S, V3 origin, V3 v) 
 __device__ __forceinline__ V3 random_cosine_direction(Rng& rng) {
     const float r1 = rng_f32(rng);
     const float r2 = rng_f32(rng);
-    const float z = sqrtf(1.0f - r2);
-    const float sr2 = sqrtf(r2);
+    const float z = sqrt_rn(1.0f - r2);
+    const float sr2 = sqrt_rn(r2);
     float sn, cs;
     sincos_turn(r1, sn, cs);  // phi = 2 pi r1
     return v3(cs * sr2, sn * sr2, z);
@@ -656,11 +682,11 @@ __device__ __forceinline__ bool shade(const SceneDev& S, const Surface& sf, V3& 
                 const float r2 = rng_f32(rng);
                 float z, radial;
                 if (use_cosine) {
-                    z = sqrtf(1.0f - r2);
-                    radial = sqrtf(r2);
+                    z = sqrt_rn(1.0f - r2);
+                    radial = sqrt_rn(r2);
                 } else {
-                    z = 1.0f + r2 * (sqrtf(1.0f - sphere_r2_over_d2) - 1.0f);
-                    radial = sqrtf(1.0f - z * z);
+                    z = 1.0f + r2 * (sqrt_rn(1.0f - sphere_r2_over_d2) - 1.0f);
+                    radial = sqrt_rn(1.0f - z * z);
                 }
                 float sn, cs;
                 sincos_turn(r1, sn, cs);  // phi = 2 pi r1
@@ -705,12 +731,12 @@ __device__ __forceinline__ bool shade(const SceneDev& S, const Surface& sf, V3& 
         const V3 unit = normalize(d);
         const float cos_theta = -fminf(dot(unit, n), 1.0f);
         // refract(), material/mod.rs:154-163
-        const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        const float sin_theta = sqrt_rn(1.0f - cos_theta * cos_theta);
         bool refracted = false;
         V3 out;
         if (!(ratio * sin_theta > 1.0f)) {
             const V3 r_out_ortho = ratio * (unit + cos_theta * n);
-            const V3 r_out_para = (-sqrtf(fabsf(1.0f - length_squared(r_out_ortho)))) * n;
+            const V3 r_out_para = (-sqrt_rn(fabsf(1.0f - length_squared(r_out_ortho)))) * n;
             const float r0 = (1.0f - ir) / (1.0f + ir);
             const float r0s = r0 * r0;
             const float reflectance = r0s + (1.0f - r0s) * powi5(1.0f - cos_theta);

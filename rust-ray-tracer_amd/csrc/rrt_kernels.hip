@@ -525,6 +525,29 @@ __global__ void k_tonemap(const float* __restrict__ accum, uint32_t width, uint3
     }
 }
 
+// Self-test of the short correctly rounded reciprocal and square root: every float bit pattern is run through
+// recip_rn / sqrt_rn and through the IEEE operations; bad[0] / bad[1] count the patterns whose results differ in
+// any bit (NaN results are compared as NaN == NaN).
+__global__ void k_check_arith(unsigned long long* __restrict__ bad) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long n_recip = 0ull, n_sqrt = 0ull;
+    // 2^20 workgroups x 256 threads x 16 patterns
+    for (uint32_t k = 0; k < 16u; ++k) {
+        const uint32_t bits = ((blockIdx.x * 16u + k) << 8) | threadIdx.x;
+        const float x = __uint_as_float(bits);
+        const float r0 = 1.0f / x, r1 = recip_rn(x);
+        const float s0 = sqrtf(x), s1 = sqrt_rn(x);
+        if (__float_as_uint(r0) != __float_as_uint(r1) && !(r0 != r0 && r1 != r1)) n_recip++;
+        if (__float_as_uint(s0) != __float_as_uint(s1) && !(s0 != s0 && s1 != s1)) n_sqrt++;
+    }
+    n_recip = wave_sum(n_recip);
+    n_sqrt = wave_sum(n_sqrt);
+    if (lane == 0u && (n_recip | n_sqrt) != 0ull) {
+        atomicAdd(&bad[0], n_recip);
+        atomicAdd(&bad[1], n_sqrt);
+    }
+}
+
 // Sums the per-chunk partial images in chunk order (deterministic, unlike float atomics).
 __global__ void k_reduce_chunks(const float* __restrict__ partial, uint32_t n_floats, uint32_t n_chunks,
                                 float* __restrict__ accum) {
@@ -654,6 +677,11 @@ hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, 
     if (inst) return launch_trace_variant<true, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
     if (count_visits) return launch_trace_variant<false, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
     return launch_trace_variant<false, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+}
+
+hipError_t launch_check_arith(unsigned long long* d_bad, hipStream_t stream) {
+    hipLaunchKernelGGL(k_check_arith, dim3(1u << 20), dim3(256), 0, stream, d_bad);
+    return hipGetLastError();
 }
 
 hipError_t launch_tonemap(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb8,
