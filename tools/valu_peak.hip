@@ -99,6 +99,20 @@ __global__ __launch_bounds__(256) void k_valu(float* out, int trips, float a, fl
 #define A_MULLO(r) "v_mul_lo_u32 " #r ", " #r ", %8\n"
 #define A_MOV(r) "v_mov_b32 " #r ", %8\n"
 #define A_LSHLOR(r) "v_lshl_or_b32 " #r ", " #r ", 16, %8\n"
+#define A_DOT2I(r) "v_dot2_i32_i16 " #r ", " #r ", %8, %9\n"
+#define A_DOT2U(r) "v_dot2_u32_u16 " #r ", " #r ", %8, %9\n"
+#define A_MADI16(r) "v_mad_i32_i16 " #r ", " #r ", %8, %9\n"
+#define A_MAXI(r) "v_max_i32 " #r ", " #r ", %8\n"
+#define A_MAX3I(r) "v_max3_i32 " #r ", " #r ", %8, %9\n"
+#define A_MAD24(r) "v_mad_i32_i24 " #r ", " #r ", %8, %9\n"
+#define A_FMAMIX(r) "v_fma_mix_f32 " #r ", " #r ", %8, %9 op_sel_hi:[1,0,0]\n"
+ONE_OP_KERNEL(k_dot2i, A_DOT2I)
+ONE_OP_KERNEL(k_dot2u, A_DOT2U)
+ONE_OP_KERNEL(k_madi16, A_MADI16)
+ONE_OP_KERNEL(k_maxi, A_MAXI)
+ONE_OP_KERNEL(k_max3i, A_MAX3I)
+ONE_OP_KERNEL(k_mad24, A_MAD24)
+ONE_OP_KERNEL(k_fmamix, A_FMAMIX)
 ONE_OP_KERNEL(k_cvt, A_CVT)
 ONE_OP_KERNEL(k_cvtb, A_CVTB)
 ONE_OP_KERNEL(k_align, A_ALIGN)
@@ -176,6 +190,13 @@ int main() {
     run<5>("v_cmp + v_cndmask", d_out, p.multiProcessorCount, ghz);
     run<6>("v_pk_fma_f32", d_out, p.multiProcessorCount, ghz);
     const int cus = p.multiProcessorCount;
+    run_one("v_dot2_i32_i16", k_dot2i, d_out, cus, ghz);
+    run_one("v_dot2_u32_u16", k_dot2u, d_out, cus, ghz);
+    run_one("v_mad_i32_i16", k_madi16, d_out, cus, ghz);
+    run_one("v_max_i32", k_maxi, d_out, cus, ghz);
+    run_one("v_max3_i32", k_max3i, d_out, cus, ghz);
+    run_one("v_mad_i32_i24", k_mad24, d_out, cus, ghz);
+    run_one("v_fma_mix_f32 (f16 src0)", k_fmamix, d_out, cus, ghz);
     run_one("v_cvt_f32_u32", k_cvt, d_out, cus, ghz);
     run_one("v_cvt_f32_ubyte1", k_cvtb, d_out, cus, ghz);
     run_one("v_alignbit_b32", k_align, d_out, cus, ghz);
