@@ -164,8 +164,8 @@ __global__ void k_refit(const Topo* __restrict__ topo, const LeafInfo* __restric
     const ChildView r = view_child(t.right, topo, leaf, tri_prefix, st, launch, node_base, tri_base);
     if (!r.ready) return;
     QNode q;
-    q.left = l.ref;
-    q.right = r.ref;
+    q.left = device_ref(l.ref);
+    q.right = device_ref(r.ref);
     quantize_box(g, l.mn, l.mx, q.lbox);
     quantize_box(g, r.mn, r.mx, q.rbox);
     nodes[node_base + i] = q;

@@ -214,7 +214,7 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     S.rects = (const RectRec*)c->d_rects; S.insts = (const InstRec*)c->d_insts; S.mats = (const MatRec*)c->d_mats;
     S.lights = (const LightRec*)c->d_lights;
     S.light_count = (uint32_t)hs.lights.size();
-    S.root = hs.root;
+    S.root = device_ref(hs.root);
     S.has_instances = hs.has_instances ? 1u : 0u;
     S.light_weight = S.light_count ? 1.0f / (float)S.light_count : 0.0f;
     S.light_zone = S.light_count ? (uint32_t)((0x100000000ull) % S.light_count) : 0u;

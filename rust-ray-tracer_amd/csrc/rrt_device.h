@@ -94,21 +94,23 @@ __host__ __device__ __forceinline__ uint32_t rng_mix(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
+// The state keeps k0 + ctr * 0x9E3779B9 as one running sum (`acc`): a draw costs an add instead of a multiply and two
+// adds, and the state is two registers.
 struct Rng {
-    uint32_t k0, k1, ctr;
+    uint32_t acc, k1;
 };
+__host__ __device__ __forceinline__ void rng_skip(Rng& r) { r.acc += 0x9E3779B9U; }  // a draw whose value is not used
 __host__ __device__ __forceinline__ Rng rng_init(uint32_t seed, uint32_t pixel, uint32_t sample) {
     Rng r;
     uint32_t h0 = rng_mix(seed ^ 0xA511E9B3U);
     uint32_t h1 = rng_mix(h0 + pixel);
-    r.k0 = rng_mix(h1 ^ (sample * 0x9E3779B9U));
-    r.k1 = rng_mix(r.k0 ^ 0x68E31DA4U ^ pixel);
-    r.ctr = 0;
+    r.acc = rng_mix(h1 ^ (sample * 0x9E3779B9U));  // k0; ctr = 0
+    r.k1 = rng_mix(r.acc ^ 0x68E31DA4U ^ pixel);
     return r;
 }
 __host__ __device__ __forceinline__ uint32_t rng_u32(Rng& r) {
-    uint32_t x = r.k0 + r.ctr * 0x9E3779B9U;
-    r.ctr++;
+    uint32_t x = r.acc;
+    r.acc += 0x9E3779B9U;
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x ^= r.k1; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
@@ -383,8 +385,8 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
     uint32_t rx = (__float_as_uint(ga.x) >> 31) << 4, ry = (__float_as_uint(ga.y) >> 31) << 4, rz = (__float_as_uint(ga.z) >> 31) << 4;
     int cur = T.cur, sp = T.sp;
     while (cur >= 0) {
-        // 32-bit byte offset from the uniform base: one shift, and the load takes the base from scalar registers
-        const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + ((uint32_t)cur << 5));
+        // an inner reference is the node's 32-bit byte offset from the uniform base, which the load takes from scalar registers
+        const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
         const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
         if (COUNT) {
             cnt.nodes++;

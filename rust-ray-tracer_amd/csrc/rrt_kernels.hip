@@ -121,7 +121,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                 rng = rng_init(S.seed, pixel, spp_offset + s);
                 const float u = (float)x + rng_f32(rng);  // main.rs:92-93
                 const float v = (float)y + rng_f32(rng);
-                rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
+                rng_skip(rng);                                // camera.rs:67: the ray time draw (unused by static scenes)
                 camera_ray(S.cam, u, v, width, height, o, d);
                 beta = v3(1.f, 1.f, 1.f);
                 radiance = v3(0.f, 0.f, 0.f);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                             rng = rng_init(S.seed, pixel, spp_offset + s);
                             const float u = (float)x + rng_f32(rng);
                             const float v = (float)y + rng_f32(rng);
-                            rng.ctr++;
+                            rng_skip(rng);
                             camera_ray(S.cam, u, v, width, height, o, d);
                             beta = v3(1.f, 1.f, 1.f);
                             radiance = v3(0.f, 0.f, 0.f);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
         V3 sum = v3(0.f, 0.f, 0.f);
         V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), beta = v3(0.f, 0.f, 0.f), radiance = v3(0.f, 0.f, 0.f);
         uint32_t depth = 0;
-        Rng rng = {0u, 0u, 0u};
+        Rng rng = {0u, 0u};
         Trav T;
         T.cur = REF_DONE;
         T.sp = 1;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                         next_sample++;
                         const float u = (float)x + rng_f32(rng);  // main.rs:92-93
                         const float v = (float)y + rng_f32(rng);
-                        rng.ctr++;                                // camera.rs:67: the ray time draw (unused by static scenes)
+                        rng_skip(rng);                                // camera.rs:67: the ray time draw (unused by static scenes)
                         camera_ray(S.cam, u, v, width, height, o, d);
                         beta = v3(1.f, 1.f, 1.f);
                         radiance = v3(0.f, 0.f, 0.f);

@@ -36,6 +36,12 @@ static constexpr uint32_t MAX_LEAF_TRIS = 8u;
 static constexpr int32_t REF_DONE = (int32_t)(REF_LEAF | (KIND_DONE << 28));
 static constexpr int32_t REF_INST_EXIT = (int32_t)(REF_LEAF | (KIND_INST_EXIT << 28));
 
+// Reference to an inner node as the device sees it: the node's byte offset from the start of the node array
+// (index * 32 < 2^30, so it stays non-negative); a fetch needs no shift.  Leaf references pass through unchanged.
+RRT_HD static inline int32_t device_ref(int32_t index_or_leaf) {
+    return index_or_leaf >= 0 ? (int32_t)((uint32_t)index_or_leaf << 5) : index_or_leaf;
+}
+
 RRT_HD static inline uint32_t make_leaf_ref(uint32_t kind, uint32_t first, uint32_t count) {
     return REF_LEAF | (kind << 28) | (((count - 1u) & 7u) << 25) | (first & REF_OFFSET_MASK);
 }
@@ -59,7 +65,7 @@ struct Grid {
 };
 
 struct alignas(16) QNode {
-    int32_t left, right;      // child references
+    int32_t left, right;      // child references: device_ref() of a node index, or a leaf reference
     uint32_t lbox[3];         // left child, per axis: bits 15..0 = min plane index, bits 31..16 = max plane index
     uint32_t rbox[3];         // right child
 };

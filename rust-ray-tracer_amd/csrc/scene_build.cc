@@ -184,7 +184,7 @@ struct Expander {
                     for (int a = 0; a < 3; ++a) rec.offset[a] = in.offset[a];
                     rec.sin_t = in.sin_theta;
                     rec.cos_t = in.cos_theta;
-                    rec.root = mi.root;
+                    rec.root = device_ref(mi.root);
                     for (int a = 0; a < 3; ++a) { rec.grid_origin[a] = mi.grid.origin[a]; rec.grid_step[a] = mi.grid.step[a]; }
                     rec.id_base = id;
                     id += mi.prim_count;
@@ -256,8 +256,8 @@ static Grid quantize_nodes(HostScene& hs, size_t first, const float* mn, const f
     for (size_t i = first; i < hs.nodes.size(); ++i) {
         const BvhNode& n = hs.nodes[i];
         QNode& q = hs.qnodes[i];
-        q.left = n.left;
-        q.right = n.right;
+        q.left = device_ref(n.left);
+        q.right = device_ref(n.right);
         quantize_box(g, n.lmin, n.lmax, q.lbox);
         quantize_box(g, n.rmin, n.rmax, q.rbox);
     }
@@ -415,6 +415,7 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     }
     hs.has_instances = !hs.insts.empty();
     if (tri_order.size() > REF_OFFSET_MASK) { err = "too many triangles"; return RRT_ERR_INVALID; }
+    if (hs.nodes.size() > (size_t)REF_OFFSET_MASK) { err = "too many BVH nodes"; return RRT_ERR_INVALID; }  // device_ref: byte offsets below 2^30
 
     hs.tris.resize(tri_order.size());
     parallel_for((uint32_t)tri_order.size(), threads, [&](uint32_t lo, uint32_t hi) {
