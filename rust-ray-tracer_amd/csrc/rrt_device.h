@@ -384,7 +384,11 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
     // being positive), else 0
     uint32_t rx = (__float_as_uint(ga.x) >> 31) << 4, ry = (__float_as_uint(ga.y) >> 31) << 4, rz = (__float_as_uint(ga.z) >> 31) << 4;
     int cur = T.cur, sp = T.sp;
-    while (cur >= 0) {
+    // The loop is uniform over the wavefront: one compare per trip decides both which lanes take the step and whether
+    // the pass goes on.
+    bool desc = cur >= 0;
+    for (;;) {
+      if (desc) {
         // an inner reference is the node's 32-bit byte offset from the uniform base, which the load takes from scalar registers
         const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
         const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
@@ -444,7 +448,10 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                 rx = (__float_as_uint(ga.x) >> 31) << 4; ry = (__float_as_uint(ga.y) >> 31) << 4; rz = (__float_as_uint(ga.z) >> 31) << 4;
             }
         }
-        if ((uint32_t)__popcll(__ballot(cur >= 0)) < min_lanes) break;
+      }
+      desc = cur >= 0;
+      const uint32_t n_desc = (uint32_t)__popcll(__ballot(desc));
+      if (n_desc == 0u || n_desc < min_lanes) break;
     }
     T.cur = cur;
     T.sp = sp;
