@@ -307,11 +307,15 @@ __device__ __forceinline__ bool first_active_lane() {
     return (unsigned)__lane_id() == (unsigned)__ffsll((long long)m) - 1u;
 }
 
+// The traversal stack is addressed as LDS (address space 3) throughout, so that every access is a ds_read / ds_write
+// and never a flat access through a generic pointer.
+typedef __attribute__((address_space(3))) int lds_int;
+
 // Resumable traversal state of one lane.  The render kernel interleaves traversal with shading of the lanes
 // that have finished, so a ray's walk can be suspended between any two steps.
 struct Trav {
     int cur;          // node / leaf reference being visited; REF_DONE when the walk is complete
-    int sp;           // stack entries in use
+    lds_int* top;     // LDS address of this lane's next free stack entry (entries are `stride` ints apart)
     Best best;
     V3 ga, gb;        // slab test constants of the ray on the current BVH's grid: plane q lies at t = q * ga + gb
     V3 ro, rd;        // ray in the current space (instanced scenes only; otherwise the world ray is used)
@@ -319,28 +323,28 @@ struct Trav {
     int32_t cur_inst; // instance record being traversed, -1 at top level
 };
 
-// The traversal stack is addressed as LDS (address space 3) throughout, so that every access is a ds_read / ds_write
-// and never a flat access through a generic pointer.
-typedef __attribute__((address_space(3))) int lds_int;
-
-// Stack access.  K == 0: all STACK_DEPTH entries of a lane live in LDS.  K > 0: LDS holds entries 0 .. K-1, which is
-// what bounds the workgroups per CU, and the entries above them live in the lane's `deep` array (private memory).
-// Walks rarely go that deep (K = 16 against typical depths of 10-14), so the extra cost is a compare per push and
-// per pop.
+// Stack access.  The stack pointer `top` is the LDS address of the lane's next free entry, so that a push or pop
+// needs no address arithmetic beyond moving it by one entry.  K == 0: all STACK_DEPTH entries of a lane live in LDS.
+// K > 0: LDS holds entries 0 .. K-1, which is what bounds the workgroups per CU, and the entries above them live in
+// the lane's `deep` array (private memory); `lim` is the address where entry K of the workgroup's first lane would
+// lie (uniform): a lane's entry e lies in LDS exactly if its address is below lim, because a lane's offset inside an
+// entry row is smaller than the row.  Walks rarely go that deep (K = 16 against typical depths of 10-14), so the
+// extra cost is a compare per push and per pop.
+__device__ __forceinline__ uint32_t lds_addr(const lds_int* p) { return (uint32_t)(size_t)p; }
 template <int K>
-__device__ __forceinline__ void stack_push(lds_int* stack, int stride, int* deep, int& sp, int v) {
-    if (K > 0 && sp >= K) deep[sp - K] = v;
-    else stack[sp * stride] = v;
-    sp++;
+__device__ __forceinline__ void stack_push(lds_int*& top, int stride, lds_int* lim, int* deep, int v) {
+    if (K > 0 && top >= lim) deep[(lds_addr(top) - lds_addr(lim)) / (uint32_t)(stride * 4)] = v;
+    else *top = v;
+    top += stride;
 }
 template <int K>
-__device__ __forceinline__ int stack_pop(lds_int* stack, int stride, int* deep, int& sp) {
-    sp--;
-    if (K == 0) return stack[sp * stride];
-    // the LDS read is unconditional (entry K-1 for a deep index): written as an either-or, the two loads are merged
-    // into one flat load through a selected generic address
-    int v = stack[(sp < K ? sp : K - 1) * stride];
-    if (sp >= K) v = deep[sp - K];
+__device__ __forceinline__ int stack_pop(lds_int*& top, int stride, lds_int* lim, int* deep) {
+    top -= stride;
+    if (K == 0) return *top;
+    // the LDS read is unconditional (some entry of row K-1 for a deep index): written as an either-or, the two loads
+    // are merged into one flat load through a selected generic address
+    int v = *(top < lim ? top : lim - stride);
+    if (top >= lim) v = deep[(lds_addr(top) - lds_addr(lim)) / (uint32_t)(stride * 4)];
     return v;
 }
 
@@ -358,14 +362,14 @@ __device__ __forceinline__ void slab_pair(uint32_t w, uint32_t rot, float a, flo
 }
 
 template <bool INST>
-__device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, lds_int* stack, Trav& T) {
+__device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, lds_int* stack, int stride, Trav& T) {
     T.best.t = tmax; T.best.id = 0xFFFFFFFFu; T.best.u = 0.f; T.best.v = 0.f; T.best.what = 0u; T.best.inst = -1;
     trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
     if (INST) { T.ro = o; T.rd = d; }
     T.id_base = 0;
     T.cur_inst = -1;
     stack[0] = REF_DONE;
-    T.sp = 1;
+    T.top = stack + stride;
     T.cur = S.root;
 }
 
@@ -377,16 +381,18 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
 // right here and keeps descending: as a leaf step of its own the change would cost the wavefront a whole pass for
 // the few lanes that need it.  `o`, `d`: the world-space ray (only read when INST).
 template <bool INST, bool COUNT, int K = 0>
-__device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, lds_int* stack, int stride, Trav& T,
-                                           TraceCounters& cnt, uint32_t min_lanes, int* deep = nullptr) {
+__device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, int stride, Trav& T,
+                                           TraceCounters& cnt, uint32_t min_lanes, lds_int* lim = nullptr, int* deep = nullptr) {
     V3 ga = T.ga, gb = T.gb;
     // rotate count of a node's plane pair: 16 where the ray runs against the axis (the sign of ga, the grid step
     // being positive), else 0
     uint32_t rx = (__float_as_uint(ga.x) >> 31) << 4, ry = (__float_as_uint(ga.y) >> 31) << 4, rz = (__float_as_uint(ga.z) >> 31) << 4;
-    int cur = T.cur, sp = T.sp;
+    int cur = T.cur;
+    lds_int* top = T.top;
     // The loop is uniform over the wavefront: one compare per trip decides both which lanes take the step and whether
     // the pass goes on.
     bool desc = cur >= 0;
+    const uint32_t min_go = min_lanes > 1u ? min_lanes : 1u;  // the pass goes on while at least this many lanes descend
     for (;;) {
       if (desc) {
         // an inner reference is the node's 32-bit byte offset from the uniform base, which the load takes from scalar registers
@@ -410,17 +416,32 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
         const float rn = fmaxf(fmaxf(fmaxf(ix, iy), iz), tmin);
         const float rf = fminf(fminf(fminf(ox, oy), oz), T.best.t);
         const bool hl = ln <= lf, hr = rn <= rf;
+        const bool any = hl || hr, both = hl && hr;
         int left = (int)a.x, right = (int)a.y;
-        if (hl && hr) {
+        if (K > 0 && __ballot(top >= lim) == 0ull) {
+            // Every lane's stack top is inside the LDS part: the step is finished without a branch.  Scalar and
+            // branch instructions take issue slots like vector ones, and the four-way case analysis below costs about
+            // 25 of them per step.  Here the far child (or, with fewer than two hits, a value nobody will read) is
+            // written above the top, the top moves up if both children are hit and down if neither is, and the entry
+            // read back is the popped one exactly when neither is hit.  Entries touched: 0 .. K-1.
+            const bool right_first = hr & (!hl | (rn < ln));  // bitwise on purpose: no short-circuit branches
+            const int near = right_first ? right : left;
+            const int far = right_first ? left : right;
+            *top = far;
+            lds_int* rd = any ? top : top - stride;
+            top = both ? top + stride : rd;
+            const int popped = *rd;
+            cur = any ? near : popped;
+        } else if (both) {
             if (rn < ln) { int tmp = left; left = right; right = tmp; }
-            stack_push<K>(stack, stride, deep, sp, right);
+            stack_push<K>(top, stride, lim, deep, right);
             cur = left;
         } else if (hl) {
             cur = left;
         } else if (hr) {
             cur = right;
         } else {
-            cur = stack_pop<K>(stack, stride, deep, sp);
+            cur = stack_pop<K>(top, stride, lim, deep);
         }
         if (INST) {
             // kinds 3..6: instance, empty child, instance exit marker (the bottom-of-stack marker, kind 7, is not)
@@ -433,7 +454,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                     trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
                     T.id_base = in.id_base;
                     T.cur_inst = (int32_t)first;
-                    stack_push<K>(stack, stride, deep, sp, REF_INST_EXIT);
+                    stack_push<K>(top, stride, lim, deep, REF_INST_EXIT);
                     cur = in.root;
                 } else {
                     if (kind == KIND_INST_EXIT) {
@@ -442,7 +463,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                         T.id_base = 0;
                         T.cur_inst = -1;
                     }
-                    cur = stack_pop<K>(stack, stride, deep, sp);
+                    cur = stack_pop<K>(top, stride, lim, deep);
                 }
                 ga = T.ga; gb = T.gb;
                 rx = (__float_as_uint(ga.x) >> 31) << 4; ry = (__float_as_uint(ga.y) >> 31) << 4; rz = (__float_as_uint(ga.z) >> 31) << 4;
@@ -450,11 +471,10 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
         }
       }
       desc = cur >= 0;
-      const uint32_t n_desc = (uint32_t)__popcll(__ballot(desc));
-      if (n_desc == 0u || n_desc < min_lanes) break;
+      if ((uint32_t)__popcll(__ballot(desc)) < min_go) break;
     }
     T.cur = cur;
-    T.sp = sp;
+    T.top = top;
 }
 
 // One leaf step (or stack marker): tests ONE primitive of the leaf with the reference's arithmetic; a triangle
@@ -462,8 +482,8 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
 // One primitive per step keeps the cost of a pass the same for every lane, whatever its leaf holds.
 // Precondition: T.cur is negative and not REF_DONE.
 template <bool INST, bool COUNT, int K = 0>
-__device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float tmin, lds_int* stack, int stride, Trav& T,
-                                          TraceCounters& cnt, int* deep = nullptr) {
+__device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float tmin, int stride, Trav& T,
+                                          TraceCounters& cnt, lds_int* lim = nullptr, int* deep = nullptr) {
     const uint32_t ref = (uint32_t)T.cur;
     const uint32_t kind = (ref >> 28) & 7u;
     const uint32_t first = ref & REF_OFFSET_MASK;
@@ -490,7 +510,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
         T.id_base = in.id_base;
         T.cur_inst = (int32_t)first;
-        stack_push<K>(stack, stride, deep, T.sp, REF_INST_EXIT);
+        stack_push<K>(T.top, stride, lim, deep, REF_INST_EXIT);
         T.cur = in.root;
         return;
     } else if (INST && kind == KIND_INST_EXIT) {
@@ -499,7 +519,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         T.id_base = 0;
         T.cur_inst = -1;
     }
-    T.cur = stack_pop<K>(stack, stride, deep, T.sp);
+    T.cur = stack_pop<K>(T.top, stride, lim, deep);
 }
 
 // Complete walk of one ray (used by the ray-batch kernel): the same passes as the render kernel, run to the end.
@@ -507,10 +527,10 @@ template <bool INST, bool COUNT>
 __device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin, float tmax, lds_int* stack, int stride,
                                       Best& best, TraceCounters& cnt) {
     Trav T;
-    trav_begin<INST>(S, o, d, tmax, stack, T);
+    trav_begin<INST>(S, o, d, tmax, stack, stride, T);
     while (T.cur != REF_DONE) {
-        trav_nodes<INST, COUNT>(S, o, d, tmin, stack, stride, T, cnt, 0u);  // 0: descend until this lane is at a leaf
-        if (T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stack, stride, T, cnt);
+        trav_nodes<INST, COUNT>(S, o, d, tmin, stride, T, cnt, 0u);  // 0: descend until this lane is at a leaf
+        if (T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stride, T, cnt);
     }
     best = T.best;
 }

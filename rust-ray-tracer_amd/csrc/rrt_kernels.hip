@@ -58,6 +58,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
     __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 16];  // per wavefront: the records of its two work items
     const uint32_t lane = threadIdx.x & 63u;
     lds_int* stack = (lds_int*)(s_stack + threadIdx.x);
+    lds_int* lim = (lds_int*)s_stack + K * RENDER_BLOCK;  // where entry K of the first lane would lie: the end of the LDS part
     int deep[STACK_DEPTH - RENDER_STACK];  // stack entries below the LDS window (private memory; rarely touched)
     const uint32_t width = G.width, height = G.height;
     const V3 bg = v3(S.background[0], S.background[1], S.background[2]);
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
             Rng rng;
             Trav T;
             T.cur = REF_DONE;
-            T.sp = 1;
+            T.top = stack;
             if (has_ray) {
                 rng = rng_init(S.seed, pixel, spp_offset + s);
                 const float u = (float)x + rng_f32(rng);  // main.rs:92-93
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                 beta = v3(1.f, 1.f, 1.f);
                 radiance = v3(0.f, 0.f, 0.f);
                 depth = S.max_depth;
-                trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
+                trav_begin<INST>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
             }
 
             for (;;) {
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
                             const uint32_t nodes0 = cnt.nodes;
-                            trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share, deep);
+                            trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
                             uint32_t steps = cnt.nodes - nodes0;
                             for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                             if (lane == 0u) {
@@ -156,10 +157,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                                 slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                             }
                         } else {
-                            trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share, deep);
+                            trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
                         }
                     }
-                    if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, deep);
+                    if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep);
                 }
                 // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
                 if (has_ray && T.cur == REF_DONE) {
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                             has_ray = false;
                         }
                     }
-                    if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
+                    if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
                 }
                 if (__ballot(has_ray) == 0ull) break;  // every lane has rendered all samples of this item
             }
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
         Rng rng = {0u, 0u};
         Trav T;
         T.cur = REF_DONE;
-        T.sp = 1;
+        T.top = stack;
 
         for (;;) {
             // ---- item rotation (touches nothing of a lane but its stage)
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share, deep);
+                        trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                         if (lane == 0u) {
@@ -290,10 +291,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                             slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                         }
                     } else {
-                        trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, share, deep);
+                        trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
                     }
                 }
-                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, stack, RENDER_BLOCK, T, cnt, deep);
+                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep);
             }
 
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev 
                         has_ray = true;
                     }
                 }
-                if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, T);
+                if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
             }
         }
     }
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, co
     V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
     Trav T;
     T.cur = REF_DONE;
-    T.sp = 1;
+    T.top = stack;
     TraceCounters cnt = {0u, 0u, 0u, 0u, 0u};
     bool exhausted = false;  // wave-uniform: the batch has no rays left to hand out
     uint32_t blk = 0u, blk_end = 0u;  // wave-uniform: the block of ray indices this wavefront hands to its lanes
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, co
                 const rrt_ray r = rays[mine];
                 o = v3(r.origin[0], r.origin[1], r.origin[2]);
                 d = v3(r.direction[0], r.direction[1], r.direction[2]);
-                trav_begin<INST>(S, o, d, tmax, stack, T);
+                trav_begin<INST>(S, o, d, tmax, stack, RENDER_BLOCK, T);
             }
             blk += take;
             continue;
@@ -489,8 +490,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, co
         const uint32_t n_walk = 64u - n_idle;
         const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
         const uint32_t share = (n_walk * node_share_64ths) >> 6;
-        if (n_desc == n_walk || n_desc >= share) trav_nodes<INST, COUNT>(S, o, d, tmin, stack, RENDER_BLOCK, T, cnt, share);
-        if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stack, RENDER_BLOCK, T, cnt);
+        if (n_desc == n_walk || n_desc >= share) trav_nodes<INST, COUNT>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share);
+        if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, RENDER_BLOCK, T, cnt);
     }
     if (COUNT) {
         const unsigned long long nn = wave_sum((unsigned long long)cnt.nodes);
