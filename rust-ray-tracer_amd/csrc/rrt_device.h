@@ -418,12 +418,13 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
         const bool hl = ln <= lf, hr = rn <= rf;
         const bool any = hl || hr, both = hl && hr;
         int left = (int)a.x, right = (int)a.y;
-        if (K > 0 && __ballot(top >= lim) == 0ull) {
+        if (K == 0 || __ballot(top >= lim) == 0ull) {
             // Every lane's stack top is inside the LDS part: the step is finished without a branch.  Scalar and
             // branch instructions take issue slots like vector ones, and the four-way case analysis below costs about
             // 25 of them per step.  Here the far child (or, with fewer than two hits, a value nobody will read) is
             // written above the top, the top moves up if both children are hit and down if neither is, and the entry
-            // read back is the popped one exactly when neither is hit.  Entries touched: 0 .. K-1.
+            // read back is the popped one exactly when neither is hit.  Entries touched: 0 .. K-1 (K == 0: the whole
+            // stack is in LDS and has one entry more than the deepest walk needs).
             const bool right_first = hr & (!hl | (rn < ln));  // bitwise on purpose: no short-circuit branches
             const int near = right_first ? right : left;
             const int far = right_first ? left : right;

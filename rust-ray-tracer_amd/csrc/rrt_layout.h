@@ -180,10 +180,11 @@ struct RenderGeom {
 // the builder bounds the combined depth of top level + bottom level to MAX_TREE_DEPTH.  39 entries x 256 lanes x
 // 4 bytes = 39 KB per workgroup, which leaves the render kernel 1 KB for its work-item records: four workgroups
 // fill the 160 KB of LDS of a CU, and four are as fast as five (measured); the depth leaves room for the linear
-// BVHs of the GPU builder (31 levels for ten million triangles).
+// BVHs of the GPU builder (33 levels for ten million triangles).
+// One entry beyond the deepest walk stays free: the branch-free node step writes a value nobody reads above the top.
 static constexpr int STACK_DEPTH = 39;
-static constexpr uint32_t MAX_TREE_DEPTH = 37;
-static_assert(MAX_TREE_DEPTH + 2 <= (uint32_t)STACK_DEPTH, "stack holds the deepest walk plus its two markers");
+static constexpr uint32_t MAX_TREE_DEPTH = 36;
+static_assert(MAX_TREE_DEPTH + 3 <= (uint32_t)STACK_DEPTH, "stack holds the deepest walk, its two markers and one free entry");
 
 }  // namespace rrt
 #endif
