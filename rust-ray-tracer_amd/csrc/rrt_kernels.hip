@@ -48,10 +48,11 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 }
 
 template <bool INST, bool COUNT, bool PIPELINED>
-__global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : 6) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+__global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
-    // Flat scenes keep RENDER_STACK entries per lane in LDS (six workgroups per CU); instanced scenes, whose kernel
+    // Flat scenes keep RENDER_STACK entries per lane in LDS (six workgroups per CU, seven in the pipelined form, whose
+    // large scenes gain more from the extra wavefront than they lose to its spills); instanced scenes, whose kernel
     // needs more registers than six or five waves per SIMD leave it, keep the whole stack there (four per CU).
     constexpr int K = INST ? 0 : RENDER_STACK;
     __shared__ int s_stack[(INST ? STACK_DEPTH : RENDER_STACK) * RENDER_BLOCK];
