@@ -113,7 +113,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
             V3 sum = v3(0.f, 0.f, 0.f);
             uint32_t s = inside ? 0u : spp;  // sample counter of this lane
             bool has_ray = s < spp;          // this lane has a ray in flight (being walked, or waiting to be shaded)
-            V3 o, d, beta, radiance;
+            V3 o, d, beta;
             uint32_t depth = 0;
             Rng rng;
             Trav T;
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                 rng_skip(rng);                                // camera.rs:67: the ray time draw (unused by static scenes)
                 camera_ray(S.cam, u, v, width, height, o, d);
                 beta = v3(1.f, 1.f, 1.f);
-                radiance = v3(0.f, 0.f, 0.f);
                 depth = S.max_depth;
                 trav_begin<INST>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
             }
@@ -168,6 +167,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                     n_rays++;
                     if (COUNT && first_active_lane()) cnt.wave_shade++;
                     bool alive;
+                    // What the path emits towards the camera.  Only the last surface of a path emits (a light or the
+                    // background; neither scatters), so the sample's radiance is this one term: no sum is carried
+                    // from bounce to bounce.
+                    V3 radiance = v3(0.f, 0.f, 0.f);
                     if (T.best.id == 0xFFFFFFFFu) {
                         radiance = radiance + mulv(beta, bg);  // ray.rs:126
                         alive = false;
@@ -187,7 +190,6 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                             rng_skip(rng);
                             camera_ray(S.cam, u, v, width, height, o, d);
                             beta = v3(1.f, 1.f, 1.f);
-                            radiance = v3(0.f, 0.f, 0.f);
                             depth = S.max_depth;
                         } else {
                             has_ray = false;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
         uint32_t left = 0;         // samples of the item not yet finished
         bool has_ray = false;    // a ray is in flight (being walked, or waiting to be shaded)
         V3 sum = v3(0.f, 0.f, 0.f);
-        V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), beta = v3(0.f, 0.f, 0.f), radiance = v3(0.f, 0.f, 0.f);
+        V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), beta = v3(0.f, 0.f, 0.f);
         uint32_t depth = 0;
         Rng rng = {0u, 0u};
         Trav T;
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
             bool take = stage == 0u || stage == 1u;  // on an item without having taken its pixel of it
             if (shade_now || take) {
                 bool alive = false;
+                V3 radiance = v3(0.f, 0.f, 0.f);  // what the path emits: one term, at its last surface (see above)
                 if (shade_now) {
                     n_rays++;
                     if (COUNT && first_active_lane()) cnt.wave_shade++;
@@ -357,7 +360,6 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                         rng_skip(rng);                                // camera.rs:67: the ray time draw (unused by static scenes)
                         camera_ray(S.cam, u, v, width, height, o, d);
                         beta = v3(1.f, 1.f, 1.f);
-                        radiance = v3(0.f, 0.f, 0.f);
                         depth = S.max_depth;
                         has_ray = true;
                     }
