@@ -418,7 +418,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
         const bool hl = ln <= lf, hr = rn <= rf;
         const bool any = hl || hr, both = hl && hr;
         int left = (int)a.x, right = (int)a.y;
-        if (K == 0 || __ballot(top >= lim) == 0ull) {
+        if (K == 0 || __builtin_expect(__ballot(top >= lim) == 0ull, 1)) {
             // Every lane's stack top is inside the LDS part: the step is finished without a branch.  Scalar and
             // branch instructions take issue slots like vector ones, and the four-way case analysis below costs about
             // 25 of them per step.  Here the far child (or, with fewer than two hits, a value nobody will read) is
