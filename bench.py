@@ -117,12 +117,12 @@ def measured_pmc(config: int, width: int, height: int, spp: int):
 
 # Issue cost in cycles of one wave-instruction on one SIMD, by instruction class, measured with tools/valu_peak.hip
 # (profiles/round1_valu_issue_rate_mi355x.txt): plain add/mul/logic/move, v_fma_f32, and the class of min/max/min3/max3,
-# sub-dword converts, bit-field and select forms.  VALU_MIX_CYCLES prices the render kernel's own mix: per ray about
-# 35 instructions of node steps (12 fma, 26 of the slow class, 9 plain per step: 3.6 cycles each), 17 of triangle tests
-# (mostly plain mul/add: 2.8) and 20 of shading and bookkeeping (3.0).
+# sub-dword converts, bit-field and select forms.  Scalar and branch instructions are not free riders: a SIMD issues about
+# one instruction of ANY kind per two cycles (tools/salu_mix.hip, profiles/round1_issue_rate_vector_scalar_mix_mi355x.txt:
+# the kernel's own mix of vector and scalar instructions, no memory operations, 2.02 cycles each at seven wavefronts per
+# SIMD), so the kernel is rated by all the instructions it issues.
 GPU_GHZ = 2.4
 VALU_CLASS_CYCLES = {"add_mul_logic": 2.5, "fma": 3.06, "minmax_convert_select": 4.3}
-VALU_MIX_CYCLES = 3.3
 
 
 def main():
@@ -254,19 +254,22 @@ def main():
                 "wave_steps_per_ray": {"node": 64 * cs.node_wave_steps / max(cs.rays, 1), "prim": 64 * cs.prim_wave_steps / max(cs.rays, 1),
                                        "shade": 64 * cs.shade_wave_passes / max(cs.rays, 1)}}
         roof["note"] = ("achieved = algorithmic bytes (nodes and primitive records the rays touch) / kernel time; the caches serve "
-                        "most of them, the HBM-side bytes per launch are `traffic`; the kernel is bound by vector-ALU issue and "
-                        "SIMD divergence (`valu`, `lane_util_*`)")
+                        "most of them, the HBM-side bytes per launch are `traffic`; the kernel is bound by instruction issue "
+                        "(vector and scalar alike) and SIMD divergence (`issue`, `lane_util_*`)")
         if pmc and "sq_insts_valu" in pmc:
-            per_simd = pmc["sq_insts_valu"] / pmc["simds"]
-            # the kernel is bound by vector-ALU issue, not by HBM: share of the launch a SIMD spends issuing VALU
-            # instructions, priced at the fma rate and at the kernel's own instruction mix
-            cycles_per_inst = k_ms * 1e-3 * GPU_GHZ * 1e9 / per_simd  # SIMD cycles of the launch per VALU instruction issued
-            roof["valu"] = {"insts_per_ray": pmc["sq_insts_valu"] / rays_per_step,
-                            "simd_cycles_per_inst": cycles_per_inst,
-                            "class_cycles": VALU_CLASS_CYCLES,
-                            "issue_frac_at_fma_rate": VALU_CLASS_CYCLES["fma"] / cycles_per_inst,
-                            "issue_frac_at_kernel_mix": VALU_MIX_CYCLES / cycles_per_inst,
-                            "source": "profiles/pmc_per_launch.json (rocprofv3 --pmc SQ_INSTS_VALU), tools/valu_peak.hip"}
+            # the kernel is bound by instruction issue, not by HBM: SIMD cycles of the launch per instruction issued
+            # (vector, scalar, LDS and vector-memory), against the same figure of a memory-free stream of the same mix
+            insts = sum(pmc.get(k, 0.0) for k in ("sq_insts_valu", "sq_insts_salu", "sq_insts_lds", "sq_insts_vmem_rd"))
+            cycles = k_ms * 1e-3 * GPU_GHZ * 1e9
+            per_inst = cycles * pmc["simds"] / insts
+            roof["issue"] = {"insts_per_ray": insts / rays_per_step,
+                             "valu_per_ray": pmc["sq_insts_valu"] / rays_per_step,
+                             "salu_per_ray": pmc.get("sq_insts_salu", 0.0) / rays_per_step,
+                             "simd_cycles_per_inst": per_inst,
+                             "peak_simd_cycles_per_inst": pmc.get("issue_peak_cycles_per_inst"),
+                             "frac_of_issue_peak": (pmc["issue_peak_cycles_per_inst"] / per_inst) if pmc.get("issue_peak_cycles_per_inst") else None,
+                             "valu_class_cycles": VALU_CLASS_CYCLES,
+                             "source": "profiles/pmc_per_launch.json (rocprofv3 --pmc SQ_INSTS_*), tools/salu_mix.hip, tools/valu_peak.hip"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(scene, width, height, spp, args.seed)
 

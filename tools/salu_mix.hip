@@ -56,7 +56,42 @@ __global__ __launch_bounds__(256) void k_branchy(float* out, int trips, float a,
     out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3;
 }
 
+// The render kernel's own mix, per group: 3 v_fma_f32, 3 of the convert / min / max class, 2 plain adds, 3 scalar
+// logic instructions (about its 72 % vector share), no memory.
+__global__ __launch_bounds__(256) void k_kernel_mix(float* out, int trips, float a, float b) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3;
+    for (int i = 0; i < trips; ++i) {
+#define KM asm volatile("v_fma_f32 %[r0], %[r0], %[a], %[b]\n s_and_b64 s[20:21], s[22:23], exec\n v_min_f32 %[r1], %[r1], %[a]\n v_fma_f32 %[r2], %[r2], %[a], %[b]\n" \
+                        "v_add_f32 %[r3], %[r3], %[a]\n s_or_b64 s[22:23], s[20:21], exec\n v_max3_f32 %[r0], %[r0], %[a], %[b]\n v_fma_f32 %[r1], %[r1], %[a], %[b]\n" \
+                        "v_cvt_f32_u32 %[r2], %[r2]\n s_xor_b64 s[20:21], s[22:23], exec\n v_add_u32 %[r3], %[r3], %[r0]\n" \
+                        : [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2), [r3] "+v"(r3) : [a] "v"(a), [b] "v"(b) : "scc", "s20", "s21", "s22", "s23");
+        KM KM KM KM KM KM KM KM
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3;
+}
+
 typedef void (*kern)(float*, int, float, float);
+static void run_total(const char* name, kern k, float* d_out, int cus, double ghz, int insts_per_trip) {
+    const int trips = 4096;
+    for (int wps = 4; wps <= 8; ++wps) {
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k, dim3(cus * wps), dim3(256), 0, 0, d_out, 64, 1.0001f, 0.5f);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k, dim3(cus * wps), dim3(256), 0, 0, d_out, trips, 1.0001f, 0.5f);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-44s waves/SIMD %d  %.3f ms  %.2f cycles per instruction (vector or scalar) per SIMD\n", name, wps, ms,
+               ms * 1e-3 * ghz * 1e9 / ((double)trips * insts_per_trip * wps));
+        fflush(stdout);
+        CHECK(hipEventDestroy(e0));
+        CHECK(hipEventDestroy(e1));
+    }
+}
 static void run(const char* name, kern k, float* d_out, int cus, double ghz, int valu_per_trip) {
     const int trips = 4096;
     for (int wps = 4; wps <= 6; wps += 2) {
@@ -94,6 +129,7 @@ int main() {
     run("4 fma, no branch chain", k_branchy<0>, d_out, cus, ghz, 32);
     run("4 fma + 1 (cmp, saveexec, branch, or exec)", k_branchy<1>, d_out, cus, ghz, 32);
     run("4 fma + 2 (cmp, saveexec, branch, or exec)", k_branchy<2>, d_out, cus, ghz, 32);
+    run_total("kernel-like mix (8 vector + 3 scalar)", k_kernel_mix, d_out, cus, ghz, 88);
     CHECK(hipFree(d_out));
     return 0;
 }
