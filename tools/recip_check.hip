@@ -1,5 +1,5 @@
 // recip_check.hip -- exhaustive check of the short correctly-rounded reciprocal used by the triangle test:
-// for EVERY positive float x the sequence  r = v_rcp_f32(x); two Newton steps with fused multiply-adds
+// for EVERY positive float x the sequence  r = v_rcp_f32(x); one Newton step in fused arithmetic
 // is compared bit for bit with the IEEE division 1.0f / x.  Prints the number of mismatches per binade range.
 //   hipcc --offload-arch=gfx950 -O2 -ffp-contract=off tools/recip_check.hip -o tools/recip_check && tools/recip_check
 #include <hip/hip_runtime.h>
@@ -20,8 +20,6 @@
 __device__ __forceinline__ float recip_short(float x) {
     float r = __builtin_amdgcn_rcpf(x);
     float e = __builtin_fmaf(-x, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    e = __builtin_fmaf(-x, r, 1.0f);
     r = __builtin_fmaf(e, r, r);
     return r;
 }
