@@ -489,6 +489,22 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
     const uint32_t kind = (ref >> 28) & 7u;
     const uint32_t first = ref & REF_OFFSET_MASK;
     const V3 ro = INST ? T.ro : o, rd = INST ? T.rd : d;
+    // The common case, decided once for the wavefront: every lane of the pass is at a triangle and the entry below
+    // its stack top is in LDS.  The step then ends without a branch: the entry below the top is read in any case and
+    // becomes current, and the top moves down, only if the leaf has no triangle left.
+    if (__builtin_expect(__ballot(kind != KIND_TRI || (K > 0 && T.top - stride >= lim)) == 0ull, 1)) {
+        test_triangle(S.tris, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+        if (COUNT) {
+            cnt.prims++;
+            if (first_active_lane()) cnt.wave_prims++;
+        }
+        const bool more = ((ref >> 25) & 7u) != 0u;
+        lds_int* down = T.top - stride;
+        const int popped = *down;
+        T.cur = more ? (int)(ref + 1u - (1u << 25)) : popped;  // next record, one triangle fewer; or the popped entry
+        T.top = more ? T.top : down;
+        return;
+    }
     if (kind == KIND_TRI) {
         test_triangle(S.tris, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
         if (COUNT) {

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                     if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
                     const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
                     const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
-                    if (n_desc == n_walk || n_desc >= share) {
+                    if (n_desc >= share) {  // share <= n_walk, so a pass in which every walker descends always runs
                         if (COUNT) {
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                 if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
                 const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
                 const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
-                if (n_desc == n_walk || n_desc >= share) {
+                if (n_desc >= share) {  // share <= n_walk, so a pass in which every walker descends always runs
                     if (COUNT) {
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, co
         const uint32_t n_walk = 64u - n_idle;
         const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
         const uint32_t share = (n_walk * node_share_64ths) >> 6;
-        if (n_desc == n_walk || n_desc >= share) trav_nodes<INST, COUNT>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share);
+        if (n_desc >= share) trav_nodes<INST, COUNT>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share);
         if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, RENDER_BLOCK, T, cnt);
     }
     if (COUNT) {
