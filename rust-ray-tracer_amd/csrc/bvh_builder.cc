@@ -1,6 +1,7 @@
 // bvh_builder.cc -- binned-SAH BVH2 over mixed primitives, depth-bounded, built on host threads.
 #include "bvh_builder.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
 #include <cfloat>
@@ -12,8 +13,19 @@ namespace rrt {
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kLeafTris = 4;      // SAH may stop at this many triangles per leaf
-constexpr float kTraversalCost = 1.0f; // cost of one node visit relative to one primitive test
+// experiment knobs (read once): RRT_LEAF_TRIS, RRT_SAH_TCOST
+static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi) {
+    const char* e = std::getenv(name);
+    if (!e) return def;
+    const long v = std::atol(e);
+    return (uint32_t)std::min<long>(std::max<long>(v, lo), hi);
+}
+static float env_f32(const char* name, float def) {
+    const char* e = std::getenv(name);
+    return e ? (float)std::atof(e) : def;
+}
+const uint32_t kLeafTris = env_u32("RRT_LEAF_TRIS", 4u, 1u, MAX_LEAF_TRIS);  // SAH may stop at this many triangles per leaf
+const float kTraversalCost = env_f32("RRT_SAH_TCOST", 1.0f);  // cost of one node visit relative to one primitive test
 
 struct Box {
     float mn[3], mx[3];

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                         trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
                     }
                 }
-                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep);
+                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep);
             }
 
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
