@@ -380,7 +380,7 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
 // In instanced scenes a lane that comes upon an instance (or upon the marker that ends one) changes its ray's space
 // right here and keeps descending: as a leaf step of its own the change would cost the wavefront a whole pass for
 // the few lanes that need it.  `o`, `d`: the world-space ray (only read when INST).
-template <bool INST, bool COUNT, int K = 0>
+template <bool INST, bool COUNT, int K = 0, bool UNROLL2 = false>
 __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes, lds_int* lim = nullptr, int* deep = nullptr) {
     V3 ga = T.ga, gb = T.gb;
@@ -393,8 +393,8 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
     // the pass goes on.
     bool desc = cur >= 0;
     const uint32_t min_go = min_lanes > 1u ? min_lanes : 1u;  // the pass goes on while at least this many lanes descend
-    for (;;) {
-      if (desc) {
+    // one node step of the lanes it is called for
+    auto step = [&]() {
         // an inner reference is the node's 32-bit byte offset from the uniform base, which the load takes from scalar registers
         const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
         const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
@@ -470,7 +470,10 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
                 rx = (__float_as_uint(ga.x) >> 31) << 4; ry = (__float_as_uint(ga.y) >> 31) << 4; rz = (__float_as_uint(ga.z) >> 31) << 4;
             }
         }
-      }
+    };
+    for (;;) {
+      if (desc) step();
+      if (UNROLL2 && cur >= 0) step();  // a second step before the pass is put to the vote again
       desc = cur >= 0;
       if ((uint32_t)__popcll(__ballot(desc)) < min_go) break;
     }
