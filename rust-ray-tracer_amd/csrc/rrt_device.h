@@ -380,7 +380,7 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
 // In instanced scenes a lane that comes upon an instance (or upon the marker that ends one) changes its ray's space
 // right here and keeps descending: as a leaf step of its own the change would cost the wavefront a whole pass for
 // the few lanes that need it.  `o`, `d`: the world-space ray (only read when INST).
-template <bool INST, bool COUNT, int K = 0, bool UNROLL2 = false>
+template <bool INST, bool COUNT, int K = 0, int STEPS = 1>
 __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes, lds_int* lim = nullptr, int* deep = nullptr) {
     V3 ga = T.ga, gb = T.gb;
@@ -473,7 +473,12 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
     };
     for (;;) {
       if (desc) step();
-      if (UNROLL2 && cur >= 0) step();  // a second step before the pass is put to the vote again
+      // further steps before the pass is put to the vote again (loop control is a tenth of a step): measured on the
+      // 1M-triangle scene, 1 / 2 / 3 / 4 steps per vote run in 175.6 / 172.1 / 170.3 / 170.9 ms
+#pragma unroll
+      for (int extra = 1; extra < STEPS; ++extra) {
+          if (cur >= 0) step();
+      }
       desc = cur >= 0;
       if ((uint32_t)__popcll(__ballot(desc)) < min_go) break;
     }
