@@ -493,8 +493,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, co
         const uint32_t n_walk = 64u - n_idle;
         const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
         const uint32_t share = (n_walk * node_share_64ths) >> 6;
-        if (n_desc >= share) trav_nodes<INST, COUNT>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share);
-        if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, RENDER_BLOCK, T, cnt);
+        if (n_desc >= share) trav_nodes<INST, COUNT, 0, 3>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share);
+        if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, 0, true>(S, o, d, tmin, RENDER_BLOCK, T, cnt);
     }
     if (COUNT) {
         const unsigned long long nn = wave_sum((unsigned long long)cnt.nodes);
