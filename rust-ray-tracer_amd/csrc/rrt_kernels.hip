@@ -149,7 +149,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
                             const uint32_t nodes0 = cnt.nodes;
-                            trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
+                            trav_nodes<INST, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
                             uint32_t steps = cnt.nodes - nodes0;
                             for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                             if (lane == 0u) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                                 slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                             }
                         } else {
-                            trav_nodes<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
+                            trav_nodes<INST, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
                         }
                     }
                     if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep);
