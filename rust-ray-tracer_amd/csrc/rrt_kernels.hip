@@ -25,6 +25,9 @@ static constexpr int WAVE = 64;
 static constexpr int RENDER_BLOCK = 256;  // 4 independent wavefronts per workgroup
 static constexpr uint32_t TRACE_BLOCK = 512;  // ray indices a wavefront of the streaming kernel draws at a time
 static constexpr int RENDER_STACK = 16;   // traversal stack entries per lane the render kernel keeps in LDS (short stack)
+// (With 20 the private remainder is 19 entries, small enough for the compiler to turn it into registers: the one-item
+// form then spills 95 of them and runs eight times slower.  Larger LDS parts bought nothing anyway: walks seldom
+// leave the first 16 entries.)
 static constexpr uint32_t N_QUEUES = 8;   // workgroup ids congruent mod 8 are dealt to one XCD and share its L2
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
