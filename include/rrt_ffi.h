@@ -15,7 +15,9 @@
  *     may free them on return).  "device" pointers (d_ prefix) are HIP device memory
  *     on the ctx's GPU; calls taking them are asynchronous on the given hipStream_t
  *     (passed as void*; NULL == the default stream).
- *   - one ctx per host thread, or external serialisation; one ctx drives one GPU.
+ *   - one ctx per host thread, or external serialisation; one ctx drives one GPU (rrt_group: several).
+ *   - at most one device call should be in flight per ctx: a device call issued on another stream than the
+ *     previous one waits (on the GPU) for that one, because both use the ctx's counters and workspace.
  *   - all floating point data is IEEE binary32; ids are 32-bit.
  *
  * Primitive ids.  The world is an ordered list of object runs (rrt_object).  Every
@@ -238,9 +240,44 @@ rrt_status rrt_render(rrt_ctx* ctx, uint32_t width, uint32_t height, uint32_t sp
                       float* accum, rrt_stats* stats);
 rrt_status rrt_render_device(rrt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
                              float* d_accum, void* stream);
+/* The same render for callers that cannot allocate.  No counterpart in the reference: it exists for hosts that may not
+ * call hipMalloc while they render (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation).  It launches the same kernels as rrt_render_device and gives bit-identical results, but its
+ * counters, work-queue heads and per-chunk partial images live in a static workspace in device memory
+ * (256 bytes + RRT_NOALLOC_PARTIAL_MAX_BYTES, held by every GPU the library runs on until the process ends) instead of
+ * buffers the context grows on demand; the call allocates and frees nothing.  A frame whose partial images
+ * (chunks x width x height x 12 bytes; a frame is cut into up to 32 sample chunks) exceed
+ * RRT_NOALLOC_PARTIAL_MAX_BYTES is refused with RRT_ERR_INVALID.  All contexts on one GPU share that GPU's workspace:
+ * calls that overlap on one GPU race (also with rrt_render_stats of an earlier such call still unread).           */
+#define RRT_NOALLOC_PARTIAL_MAX_BYTES (64u << 20)
+rrt_status rrt_render_device_noalloc(rrt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
+                                     float* d_accum, void* stream);
 /* Blocks until the stream of the last rrt_render_device or rrt_intersect_device call has drained, then reports
  * its counters (for a ray batch: rays = n, samples = 0). */
 rrt_status rrt_render_stats(rrt_ctx* ctx, rrt_stats* stats);
+
+/* ---- multi-GPU ----  replaces: the rayon pool over image rows (reference src/main.rs:42-49,86), the reference's
+ * only parallelism, across the GPUs of one node.  A group is one context per listed device inside one host process.
+ * Every sample is independent (reference src/main.rs:91), so rrt_group_render gives member g a contiguous slice of
+ * the sample indices [spp_offset, spp_offset + spp_total) of every pixel (remainder to the low members), renders the
+ * slices side by side, sums the f32 accumulation buffers on member 0 (RCCL ncclReduce over xGMI when the devices
+ * are distinct; librccl is opened at run time, only then; a copy plus an add kernel when devices repeat or RCCL is
+ * unavailable) and copies the sum to `accum` (host, layout as rrt_render).  The scene is built once on the host and
+ * uploaded to every member.  Listing one device twice is allowed (two members share the GPU): a rehearsal of the
+ * partition on a one-GPU machine, not a speed-up.  stats: counters summed over members, kernel_ms = the slowest.   */
+typedef struct rrt_group rrt_group;
+rrt_status rrt_group_create(const rrt_config* cfg /* .device ignored */, const int32_t* devices, uint32_t n_devices,
+                            rrt_group** out);
+void rrt_group_destroy(rrt_group* group);
+const char* rrt_group_last_error(const rrt_group* group);
+uint32_t rrt_group_size(const rrt_group* group);
+const char* rrt_group_reduce_path(const rrt_group* group); /* "none" (one member), "rccl" or "copy+add" */
+rrt_status rrt_group_scene_upload(rrt_group* group, const rrt_scene_desc* scene);
+rrt_status rrt_group_scene_get_info(const rrt_group* group, rrt_scene_info* out);
+rrt_status rrt_group_render(rrt_group* group, uint32_t width, uint32_t height, uint32_t spp_total, uint32_t spp_offset,
+                            float* accum, rrt_stats* stats);
+rrt_status rrt_group_tonemap(rrt_group* group, const float* accum, uint32_t width, uint32_t height, uint32_t spp_total,
+                             uint8_t* rgb8);
 
 /* ---- tone map ----  replaces: `get_color(color, samples)` + the flipped `put_pixel`
  * (reference src/vec3.rs:30-53, src/main.rs:104-109).  rgb8 is top-down, w*h*3 bytes.        */

@@ -69,7 +69,12 @@ static uint32_t rng_next(rng_t* r) {
 }
 /* rand 0.8.3 Standard: f32 from the top 24 bits */
 static float gen_f32(rng_t* r) { return (float)(rng_next(r) >> 8) * (1.0f / 16777216.0f); }
-/* rand 0.8.3 UniformFloat::sample_single: value in [1,2) from 23 bits, minus 1, times scale, plus low */
+/* rand 0.8.3 `gen_range(low..high)` for f32 = UniformFloat::sample_single (rand-0.8.3 src/distributions/uniform.rs):
+ * a value in [1,2) from the top 23 bits, minus 1, times scale = high - low, plus low; if rounding carried the result up
+ * to `high`, scale is decreased by one ulp and another value is drawn.  (Uniform::new(..).sample(), which the
+ * reference does not use, is the other formula: value1_2 * scale + (low - scale).)  rand loops without a bound; here the
+ * loop gives up after 8 draws and returns low -- with the decreasing scale the second draw already succeeds unless it
+ * is again the largest of the 2^23 values. */
 static float gen_range_f32(rng_t* r, float low, float high) {
     float scale = high - low;
     int tries;
@@ -79,6 +84,10 @@ static float gen_range_f32(rng_t* r, float low, float high) {
         memcpy(&v12, &bits, 4);
         float res = (v12 - 1.0f) * scale + low;
         if (res < high) return res;
+        uint32_t sb;
+        memcpy(&sb, &scale, 4);
+        sb -= 1u; /* decrease_masked: the next float below */
+        memcpy(&scale, &sb, 4);
     }
     return low;
 }
@@ -380,6 +389,21 @@ static int aabb_hit(vec3 bmin, vec3 bmax, ray_t r, float t_min, float t_max) {
     }
     return 1;
 }
+/* A slab test that does carry the interval from axis to axis (what the reference's loop presumably meant to be):
+ * used only for the second, clearly labelled CPU baseline, which walks the same reference-style tree with a box test
+ * that actually culls.  Not the reference's behaviour. */
+static int aabb_hit_running(vec3 bmin, vec3 bmax, ray_t r, float t_min, float t_max) {
+    for (unsigned a = 0; a < 3; ++a) {
+        float inv_d = 1.0f / vget(r.d, a);
+        float t0 = (vget(bmin, a) - vget(r.o, a)) * inv_d;
+        float t1 = (vget(bmax, a) - vget(r.o, a)) * inv_d;
+        if (inv_d < 0.0f) { float tmp = t0; t0 = t1; t1 = tmp; }
+        t_min = rust_max(t0, t_min);
+        t_max = rust_min(t1, t_max);
+        if (t_max <= t_min) return 0;
+    }
+    return 1;
+}
 typedef struct { uint32_t idx; float key; } sort_item;
 static int cmp_item(const void* a, const void* b) {
     float x = ((const sort_item*)a)->key, y = ((const sort_item*)b)->key;
@@ -444,27 +468,33 @@ int oracle_scene_build_ref_bvh(oracle_scene* s, uint32_t axis_seed) {
     return 0;
 }
 /* src/geometry/mod.rs:136-153 */
-static int bvh_hit(const oracle_scene* s, const bvh_node* n, ray_t r, float t_min, float t_max, hitrec* rec) {
+static int bvh_hit(const oracle_scene* s, const bvh_node* n, ray_t r, float t_min, float t_max, hitrec* rec, int running) {
     if (n->leaf_prim >= 0) {
         hitrec tmp;
         memset(&tmp, 0, sizeof tmp);
         if (hit_prim(&s->prims[n->leaf_prim], r, t_min, t_max, &tmp)) { *rec = tmp; rec->prim = n->leaf_prim; return 1; }
         return 0;
     }
-    if (!aabb_hit(n->bmin, n->bmax, r, t_min, t_max)) return 0;
+    if (!(running ? aabb_hit_running(n->bmin, n->bmax, r, t_min, t_max) : aabb_hit(n->bmin, n->bmax, r, t_min, t_max))) return 0;
     hitrec l, rr;
-    if (bvh_hit(s, n->left, r, t_min, t_max, &l)) {
-        if (bvh_hit(s, n->right, r, t_min, l.t, &rr)) { *rec = rr; return 1; }
+    if (bvh_hit(s, n->left, r, t_min, t_max, &l, running)) {
+        if (bvh_hit(s, n->right, r, t_min, l.t, &rr, running)) { *rec = rr; return 1; }
         *rec = l;
         return 1;
     }
-    if (bvh_hit(s, n->right, r, t_min, t_max, &rr)) { *rec = rr; return 1; }
+    if (bvh_hit(s, n->right, r, t_min, t_max, &rr, running)) { *rec = rr; return 1; }
     return 0;
 }
 
-enum { HIT_BRUTE = 0, HIT_REF_BVH = 1 };
+/* HIT_REF_BVH: the reference's tree and box test.  HIT_REF_BVH_RUNNING_SLAB: the same tree with aabb_hit_running. */
+enum { HIT_BRUTE = 0, HIT_REF_BVH = 1, HIT_REF_BVH_RUNNING_SLAB = 2 };
 static int world_hit(const oracle_scene* s, int mode, ray_t r, float t_min, float t_max, hitrec* rec) {
-    if (mode == HIT_REF_BVH && s->root) { rec->hit = 0; rec->prim = -1; int h = bvh_hit(s, s->root, r, t_min, t_max, rec); rec->hit = h; return h; }
+    if ((mode == HIT_REF_BVH || mode == HIT_REF_BVH_RUNNING_SLAB) && s->root) {
+        rec->hit = 0; rec->prim = -1;
+        int h = bvh_hit(s, s->root, r, t_min, t_max, rec, mode == HIT_REF_BVH_RUNNING_SLAB);
+        rec->hit = h;
+        return h;
+    }
     return closest_brute(s, r, t_min, t_max, rec);
 }
 
@@ -695,6 +725,60 @@ static vec3 ray_color(const oracle_scene* s, int mode, ray_t ray, uint32_t depth
         return vadd(emitted, vdivs(vscale(s_pdf, vmul(rgb, next)), pdf_val));
     }
     return s->background;
+}
+
+/* ------------------------------------------------------------------ exports for the known-answer tests */
+/* n draws of gen_range(low..high) from the stream (seed, pixel, sample) */
+void oracle_gen_range_f32(uint32_t seed, uint32_t pixel, uint32_t sample, float low, float high, uint32_t n, float* out) {
+    rng_t r = rng_start(seed, pixel, sample);
+    for (uint32_t i = 0; i < n; ++i) out[i] = gen_range_f32(&r, low, high);
+}
+/* the value gen_range maps a given 32-bit draw to on its first try (before the `< high` test), and whether it passes */
+int oracle_gen_range_map(uint32_t draw, float low, float high, float* out) {
+    uint32_t bits = (draw >> 9) | 0x3f800000U;
+    float v12;
+    memcpy(&v12, &bits, 4);
+    *out = (v12 - 1.0f) * (high - low) + low;
+    return *out < high;
+}
+/* OrthNormBasis::from_w, src/vec3.rs:59-68: out = u, v, w */
+void oracle_onb(const float* n, float* out) {
+    onb_t o = onb_from_w(V(n[0], n[1], n[2]));
+    out[0] = o.u.x; out[1] = o.u.y; out[2] = o.u.z; out[3] = o.v.x; out[4] = o.v.y; out[5] = o.v.z; out[6] = o.w.x; out[7] = o.w.y; out[8] = o.w.z;
+}
+float oracle_reflectance(float cosine, float ref_idx) { return reflectance(cosine, ref_idx); }
+int oracle_refract(const float* uv, const float* n, float ratio, float* out) {
+    vec3 r = V(0.f, 0.f, 0.f);
+    int ok = refract(V(uv[0], uv[1], uv[2]), V(n[0], n[1], n[2]), ratio, &r);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+    return ok;
+}
+void oracle_reflect(const float* v, const float* n, float* out) {
+    vec3 r = reflect(V(v[0], v[1], v[2]), V(n[0], n[1], n[2]));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+/* Hittables::pdf_value of the scene's light list for a direction v from origin */
+float oracle_lights_pdf(const oracle_scene* s, const float* origin, const float* v) {
+    if (s->n_lights == 0) return 0.0f;
+    return lights_pdf_value(s, V(origin[0], origin[1], origin[2]), V(v[0], v[1], v[2]));
+}
+/* n directions of Hittables::random from origin (stream (seed, pixel, sample)) */
+void oracle_lights_random(const oracle_scene* s, const float* origin, uint32_t seed, uint32_t n, float* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        rng_t r = rng_start(seed, i, 0);
+        vec3 d = lights_random(s, V(origin[0], origin[1], origin[2]), &r);
+        out[3 * i] = d.x; out[3 * i + 1] = d.y; out[3 * i + 2] = d.z;
+    }
+}
+/* n cosine-lobe directions around normal (pdf.rs:14-26,46-48) and the lobe's pdf value for each (pdf.rs:41-44) */
+void oracle_cosine_samples(const float* normal, uint32_t seed, uint32_t n, float* dirs, float* pdfs) {
+    onb_t uvw = onb_from_w(V(normal[0], normal[1], normal[2]));
+    for (uint32_t i = 0; i < n; ++i) {
+        rng_t r = rng_start(seed, i, 0);
+        vec3 d = onb_local(&uvw, random_cosine_direction(&r));
+        dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
+        pdfs[i] = cosine_pdf_value(&uvw, d);
+    }
 }
 
 /* ------------------------------------------------------------------ render loop, src/main.rs:86-103 */

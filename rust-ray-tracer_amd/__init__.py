@@ -143,7 +143,11 @@ ABI_SYMBOLS = [
     "rrt_scene_check",
     "rrt_intersect", "rrt_intersect_device", "rrt_render", "rrt_render_device", "rrt_render_stats", "rrt_tonemap",
     "rrt_tonemap_device", "rrt_selftest_arith", "rrt_gltf_load", "rrt_scene_free", "rrt_png_write",
+    "rrt_render_device_noalloc",
+    "rrt_group_create", "rrt_group_destroy", "rrt_group_last_error", "rrt_group_size", "rrt_group_reduce_path",
+    "rrt_group_scene_upload", "rrt_group_scene_get_info", "rrt_group_render", "rrt_group_tonemap",
 ]
+NOALLOC_PARTIAL_MAX_BYTES = 64 << 20  # RRT_NOALLOC_PARTIAL_MAX_BYTES
 
 _lib = None
 
@@ -170,7 +174,21 @@ def load_library() -> C.CDLL:
     lib.rrt_intersect_device.argtypes = [vp, vp, C.c_size_t, f32, f32, vp, vp]
     lib.rrt_render.argtypes = [vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
     lib.rrt_render_device.argtypes = [vp, u32, u32, u32, u32, vp, vp]
+    lib.rrt_render_device_noalloc.argtypes = [vp, u32, u32, u32, u32, vp, vp]
     lib.rrt_render_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.rrt_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int32), u32, C.POINTER(vp)]
+    lib.rrt_group_destroy.argtypes = [vp]
+    lib.rrt_group_destroy.restype = None
+    lib.rrt_group_last_error.argtypes = [vp]
+    lib.rrt_group_last_error.restype = C.c_char_p
+    lib.rrt_group_size.argtypes = [vp]
+    lib.rrt_group_size.restype = u32
+    lib.rrt_group_reduce_path.argtypes = [vp]
+    lib.rrt_group_reduce_path.restype = C.c_char_p
+    lib.rrt_group_scene_upload.argtypes = [vp, C.POINTER(SceneDescPOD)]
+    lib.rrt_group_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
+    lib.rrt_group_render.argtypes = [vp, u32, u32, u32, u32, vp, C.POINTER(Stats)]
+    lib.rrt_group_tonemap.argtypes = [vp, vp, u32, u32, u32, vp]
     lib.rrt_tonemap.argtypes = [vp, vp, u32, u32, u32, vp]
     lib.rrt_tonemap_device.argtypes = [vp, vp, u32, u32, u32, vp, vp]
     lib.rrt_selftest_arith.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -503,6 +521,10 @@ class Renderer:
     def render_device(self, width: int, height: int, spp: int, spp_offset: int, d_accum: int, stream: int = 0):
         _check(self.lib.rrt_render_device(self.ctx, width, height, spp, spp_offset, d_accum, stream), self.ctx)
 
+    def render_device_noalloc(self, width: int, height: int, spp: int, spp_offset: int, d_accum: int, stream: int = 0):
+        """``rrt_render_device`` out of the library's static workspace: allocates nothing, refuses large frames."""
+        _check(self.lib.rrt_render_device_noalloc(self.ctx, width, height, spp, spp_offset, d_accum, stream), self.ctx)
+
     def render_stats(self) -> Stats:
         st = Stats()
         _check(self.lib.rrt_render_stats(self.ctx, C.byref(st)), self.ctx)
@@ -524,6 +546,64 @@ class Renderer:
         a, b = C.c_uint64(0), C.c_uint64(0)
         _check(self.lib.rrt_selftest_arith(self.ctx, C.byref(a), C.byref(b)), self.ctx)
         return a.value, b.value
+
+
+class RendererGroup:
+    """Several GPUs in one process (``rrt_group_*``): the sample range of a frame is split over the members, the
+    accumulation buffers are summed on member 0.  Stands for the reference's rayon pool (``src/main.rs:42-49,86``)."""
+
+    def __init__(self, devices: Sequence[int], seed: int = 1, max_depth: int = 4, t_min: float = 1e-4,
+                 count_visits: bool = False, device_build: bool = False):
+        self.lib = load_library()
+        cfg = Config(0, seed, max_depth, t_min,
+                     (CFG_COUNT_VISITS if count_visits else 0) | (CFG_DEVICE_BUILD if device_build else 0))
+        devs = (C.c_int32 * len(devices))(*devices)
+        self.grp = C.c_void_p()
+        _check(self.lib.rrt_group_create(C.byref(cfg), devs, len(devices), C.byref(self.grp)), None)
+
+    def _check(self, status: int):
+        if status != RRT_OK:
+            msg = self.lib.rrt_group_last_error(self.grp)
+            raise RrtError(status, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "grp", None) is not None and self.grp:
+            self.lib.rrt_group_destroy(self.grp)
+            self.grp = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self) -> int:
+        return self.lib.rrt_group_size(self.grp)
+
+    @property
+    def reduce_path(self) -> str:
+        return self.lib.rrt_group_reduce_path(self.grp).decode()
+
+    def upload(self, scene: Scene) -> SceneInfo:
+        d = scene.desc()
+        self._check(self.lib.rrt_group_scene_upload(self.grp, C.byref(d)))
+        info = SceneInfo()
+        self._check(self.lib.rrt_group_scene_get_info(self.grp, C.byref(info)))
+        return info
+
+    def render(self, width: int, height: int, spp_total: int, spp_offset: int = 0):
+        accum = np.zeros((height, width, 3), np.float32)
+        st = Stats()
+        self._check(self.lib.rrt_group_render(self.grp, width, height, spp_total, spp_offset, accum.ctypes.data, C.byref(st)))
+        return accum, st
+
+    def tonemap(self, accum: np.ndarray, spp_total: int) -> np.ndarray:
+        accum = np.ascontiguousarray(accum, dtype=np.float32)
+        h, w, _ = accum.shape
+        rgb = np.zeros((h, w, 3), np.uint8)
+        self._check(self.lib.rrt_group_tonemap(self.grp, accum.ctypes.data, w, h, spp_total, rgb.ctypes.data))
+        return rgb
 
 
 def png_write(path: str, rgb8: np.ndarray):

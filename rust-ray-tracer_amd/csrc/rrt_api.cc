@@ -1,9 +1,12 @@
 // rrt_api.cc -- implementation of the C ABI in include/rrt_ffi.h (context, scene upload, launches).
-#include <hip/hip_runtime_api.h>
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened at run time, when a group spans several GPUs
 
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -25,6 +28,19 @@ namespace rrt {
 void set_thread_error(const std::string& msg) { g_thread_error = msg; }
 }  // namespace rrt
 
+// Static workspace of rrt_render_device_noalloc: the counter block (256 bytes: ray and visit counters, work-queue
+// heads) followed by the per-chunk partial images.  Every GPU the library runs on holds its own copy of the array at
+// its own address until the process ends; host code never uses the array's name as an address, only the pointer
+// hipGetSymbolAddress returns for the current device (looked up once per device in rrt_create).
+static constexpr size_t NOALLOC_COUNTER_BYTES = 256;
+static constexpr size_t NOALLOC_PARTIAL_BYTES = (size_t)RRT_NOALLOC_PARTIAL_MAX_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_COUNTER_BYTES + NOALLOC_PARTIAL_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+unsigned char* g_scratch_ptr[MAX_DEVICES] = {};  // per device ordinal: address of that device's `scratch`
+}  // namespace
+
 struct rrt_ctx {
     rrt_config cfg{};
     std::string err;
@@ -40,6 +56,11 @@ struct rrt_ctx {
     size_t partial_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipStream_t last_stream = nullptr;
+    unsigned long long* last_counters = nullptr;  // the counter block the pending call used (d_counters, or the static one)
+    unsigned char* d_static = nullptr;            // this device's copy of the static workspace
+    // grow-only staging buffers of the host-pointer variants (rrt_render, rrt_intersect, rrt_tonemap)
+    void* d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes[2] = {0, 0};
     bool render_pending = false;
     uint64_t pending_samples = 0;
     uint64_t pending_rays = 0;  // ray count of a pending ray batch (its kernel does not count rays itself)
@@ -79,6 +100,28 @@ rrt_status upload(rrt_ctx* c, const std::vector<T>& v, void** dst, uint64_t& tot
     RRT_HIP(c, hipMemset(*dst, 0, bytes));
     if (!v.empty()) RRT_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     total += bytes;
+    return RRT_OK;
+}
+
+// Grow-only device staging buffer `slot` of the host-pointer entry points: allocated on first use, reused afterwards,
+// so that repeated rrt_render / rrt_intersect / rrt_tonemap calls do not pay a hipMalloc / hipFree pair each.
+rrt_status stage(rrt_ctx* c, int slot, size_t bytes, void** out) {
+    if (bytes > c->stage_bytes[slot]) {
+        RRT_HIP(c, hipDeviceSynchronize());  // the old buffer may still be in use by a call in flight
+        if (c->d_stage[slot]) (void)hipFree(c->d_stage[slot]);
+        c->d_stage[slot] = nullptr;
+        c->stage_bytes[slot] = 0;
+        RRT_HIP(c, hipMalloc(&c->d_stage[slot], bytes));
+        c->stage_bytes[slot] = bytes;
+    }
+    *out = c->d_stage[slot];
+    return RRT_OK;
+}
+
+// A device call on stream `s` shares the context's counter block, work-queue heads, partial images and events with the
+// previous one: if that one was issued on another stream and may still be running, `s` waits for it first.
+rrt_status order_after_pending(rrt_ctx* c, hipStream_t s) {
+    if (c->render_pending && s != c->last_stream) RRT_HIP(c, hipStreamWaitEvent(s, c->ev_stop, 0));
     return RRT_OK;
 }
 
@@ -123,6 +166,19 @@ rrt_status rrt_create(const rrt_config* cfg, rrt_ctx** out) {
         rrt_destroy(c);
         return st;
     }
+    // address of THIS device's copy of the static workspace (the device is current); looked up once per device
+    if (cfg->device < MAX_DEVICES) {
+        if (!g_scratch_ptr[cfg->device]) {
+            unsigned char* ptr = nullptr;
+            if ((e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch))) != hipSuccess || !ptr) {
+                rrt_status st = hip_fail(nullptr, e, "rrt_create: hipGetSymbolAddress(scratch)");
+                rrt_destroy(c);
+                return st;
+            }
+            g_scratch_ptr[cfg->device] = ptr;
+        }
+        c->d_static = g_scratch_ptr[cfg->device];
+    }
     *out = c;
     return RRT_OK;
 }
@@ -133,12 +189,17 @@ void rrt_destroy(rrt_ctx* c) {
     free_scene(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    for (void* b : c->d_stage) if (b) (void)hipFree(b);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
     delete c;
 }
 
-rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
+}  // extern "C"
+
+// Scene upload proper.  `prebuilt`: a host scene already built from `scene` without deferred BVHs (a group builds it
+// once and uploads it to every member), or NULL to build it here.
+static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, HostScene* prebuilt) {
     if (!c) return set_err(nullptr, RRT_ERR_INVALID, "rrt_scene_upload: ctx is NULL");
     if (!scene) return set_err(c, RRT_ERR_INVALID, "rrt_scene_upload: scene is NULL");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
@@ -148,21 +209,24 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
         device_min = 4096;
         if (const char* e = std::getenv("RRT_DEVICE_BUILD_MIN")) device_min = (uint32_t)std::max(2, std::atoi(e));
     }
-    HostScene hs;
+    HostScene local;
+    HostScene& hs = prebuilt ? *prebuilt : local;
     std::string err;
     rrt_status st;
     uint64_t total = 0;
     float build_ms = 0.f, upload_ms = 0.f;
     for (;;) {
         const auto t0 = std::chrono::steady_clock::now();
-        try {
-            st = build_host_scene(scene, hs, err, build_threads(), device_min);
-        } catch (const std::bad_alloc&) {
-            return set_err(c, RRT_ERR_OOM, "rrt_scene_upload: out of host memory while building the BVH");
-        } catch (const std::exception& ex) {
-            return set_err(c, RRT_ERR_INVALID, std::string("rrt_scene_upload: ") + ex.what());
+        if (!prebuilt) {
+            try {
+                st = build_host_scene(scene, hs, err, build_threads(), device_min);
+            } catch (const std::bad_alloc&) {
+                return set_err(c, RRT_ERR_OOM, "rrt_scene_upload: out of host memory while building the BVH");
+            } catch (const std::exception& ex) {
+                return set_err(c, RRT_ERR_INVALID, std::string("rrt_scene_upload: ") + ex.what());
+            }
+            if (st != RRT_OK) return set_err(c, st, "rrt_scene_upload: " + err);
         }
-        if (st != RRT_OK) return set_err(c, st, "rrt_scene_upload: " + err);
         const auto t1 = std::chrono::steady_clock::now();
 
         RRT_HIP(c, hipDeviceSynchronize());
@@ -236,6 +300,10 @@ rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) {
     return RRT_OK;
 }
 
+extern "C" {
+
+rrt_status rrt_scene_upload(rrt_ctx* c, const rrt_scene_desc* scene) { return scene_upload_impl(c, scene, nullptr); }
+
 rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
     if (!scene || !out) return set_err(nullptr, RRT_ERR_INVALID, "rrt_scene_check: NULL argument");
     HostScene hs;
@@ -283,6 +351,7 @@ rrt_status rrt_intersect_device(rrt_ctx* c, const rrt_ray* d_rays, size_t n, flo
     RenderTuning tuning;
     if (const char* e = std::getenv("RRT_NODE_SHARE")) tuning.node_share_64ths = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RRT_REFILL_MIN")) tuning.refill_min = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+    if (rrt_status st = order_after_pending(c, s)) return st;
     RRT_HIP(c, hipMemsetAsync(c->d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
     RRT_HIP(c, launch_intersect(c->sdev, d_rays, n, t_min, t_max, d_out, c->d_counters,
@@ -293,6 +362,7 @@ rrt_status rrt_intersect_device(rrt_ctx* c, const rrt_ray* d_rays, size_t n, flo
     c->render_pending = true;
     c->pending_samples = 0;
     c->pending_rays = n;
+    c->last_counters = c->d_counters;
     return RRT_OK;
 }
 
@@ -301,30 +371,34 @@ rrt_status rrt_intersect(rrt_ctx* c, const rrt_ray* rays, size_t n, float t_min,
     if (!c->has_scene) return set_err(c, RRT_ERR_STATE, "rrt_intersect: no scene uploaded");
     if (n == 0) return RRT_OK;
     if (!rays || !out) return set_err(c, RRT_ERR_INVALID, "rrt_intersect: NULL buffer");
+    if (n > 0xF0000000ull) return set_err(c, RRT_ERR_INVALID, "rrt_intersect: batch too large");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
-    rrt_ray* d_rays = nullptr;
-    rrt_hit* d_hits = nullptr;
-    hipError_t e = hipMalloc((void**)&d_rays, n * sizeof(rrt_ray));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_hits, n * sizeof(rrt_hit));
-    if (e == hipSuccess) e = hipMemcpy(d_rays, rays, n * sizeof(rrt_ray), hipMemcpyHostToDevice);
-    rrt_status st = RRT_OK;
-    if (e == hipSuccess) st = rrt_intersect_device(c, d_rays, n, t_min, t_max, d_hits, nullptr);
-    if (e == hipSuccess && st == RRT_OK) e = hipDeviceSynchronize();
-    if (e == hipSuccess && st == RRT_OK) e = hipMemcpy(out, d_hits, n * sizeof(rrt_hit), hipMemcpyDeviceToHost);
-    if (d_rays) (void)hipFree(d_rays);
-    if (d_hits) (void)hipFree(d_hits);
-    if (e != hipSuccess) return hip_fail(c, e, "rrt_intersect");
-    return st;
+    void *d_rays = nullptr, *d_hits = nullptr;
+    rrt_status st;
+    if ((st = stage(c, 0, n * sizeof(rrt_ray), &d_rays)) != RRT_OK || (st = stage(c, 1, n * sizeof(rrt_hit), &d_hits)) != RRT_OK) return st;
+    RRT_HIP(c, hipMemcpy(d_rays, rays, n * sizeof(rrt_ray), hipMemcpyHostToDevice));
+    if ((st = rrt_intersect_device(c, (const rrt_ray*)d_rays, n, t_min, t_max, (rrt_hit*)d_hits, nullptr)) != RRT_OK) return st;
+    RRT_HIP(c, hipStreamSynchronize(nullptr));
+    RRT_HIP(c, hipMemcpy(out, d_hits, n * sizeof(rrt_hit), hipMemcpyDeviceToHost));
+    return RRT_OK;
 }
 
-rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
-                             float* d_accum, void* stream) {
-    if (!c) return set_err(nullptr, RRT_ERR_INVALID, "rrt_render_device: ctx is NULL");
-    if (!c->has_scene) return set_err(c, RRT_ERR_STATE, "rrt_render_device: no scene uploaded");
-    if (!d_accum) return set_err(c, RRT_ERR_INVALID, "rrt_render_device: accum is NULL");
-    if (width == 0 || height == 0 || spp == 0) return set_err(c, RRT_ERR_INVALID, "rrt_render_device: width, height and spp must be > 0");
-    if ((uint64_t)width * height > 0x7FFFFFFFull) return set_err(c, RRT_ERR_INVALID, "rrt_render_device: image too large");
-    if ((uint64_t)spp + spp_offset > 0xFFFFFFFFull) return set_err(c, RRT_ERR_INVALID, "rrt_render_device: sample index overflows");
+}  // extern "C"
+
+// Shared body of rrt_render_device and rrt_render_device_noalloc.  `noalloc`: counters, work-queue heads and partial
+// images live in the device's static workspace and nothing is allocated; frames whose partial images exceed that
+// workspace are refused.
+static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset, float* d_accum,
+                              void* stream, bool noalloc, const char* fn) {
+    const std::string who = fn;
+    if (!c) return set_err(nullptr, RRT_ERR_INVALID, who + ": ctx is NULL");
+    if (!c->has_scene) return set_err(c, RRT_ERR_STATE, who + ": no scene uploaded");
+    if (!d_accum) return set_err(c, RRT_ERR_INVALID, who + ": accum is NULL");
+    if (width == 0 || height == 0 || spp == 0) return set_err(c, RRT_ERR_INVALID, who + ": width, height and spp must be > 0");
+    // the kernels index the image's floats with 32 bits
+    if ((uint64_t)width * height > (0xFFFFFFFFull - 255ull) / 3ull) return set_err(c, RRT_ERR_INVALID, who + ": image too large");
+    if ((uint64_t)spp + spp_offset > 0xFFFFFFFFull) return set_err(c, RRT_ERR_INVALID, who + ": sample index overflows");
+    if (noalloc && !c->d_static) return set_err(c, RRT_ERR_STATE, who + ": no static workspace on this device");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     hipStream_t s = (hipStream_t)stream;
     // Scenes with a real hierarchy (>= 4096 nodes): paths bounce and walks are long, so items of 8 samples, the
@@ -336,15 +410,34 @@ rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32
         if (v >= 1) n_chunks = std::min<uint32_t>((uint32_t)v, spp);
     }
     while (n_chunks > 1u && (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * n_chunks > 0x7FFFFFFFull) n_chunks /= 2u;
+    // No chunk may be empty: a chunk holds ceil(spp / n_chunks) samples, so only ceil(spp / that) chunks have any
+    // (50 samples in 12 chunks are 10 chunks of 5), and the kernel writes a partial image only for chunks with samples.
+    {
+        const uint32_t chunk_spp = (spp + n_chunks - 1u) / n_chunks;
+        n_chunks = (spp + chunk_spp - 1u) / chunk_spp;
+    }
     const size_t need = n_chunks > 1u ? (size_t)n_chunks * width * height * 3u * sizeof(float) : 0u;
-    if (need > c->partial_bytes) {
-        // the old workspace may still be read by a render in flight on another stream
-        RRT_HIP(c, hipDeviceSynchronize());
-        if (c->d_partial) (void)hipFree(c->d_partial);
-        c->d_partial = nullptr;
-        c->partial_bytes = 0;
-        RRT_HIP(c, hipMalloc((void**)&c->d_partial, need));
-        c->partial_bytes = need;
+    float* d_partial = nullptr;
+    unsigned long long* d_counters = nullptr;
+    if (noalloc) {
+        if (need > NOALLOC_PARTIAL_BYTES)
+            return set_err(c, RRT_ERR_INVALID, who + ": this frame needs " + std::to_string(need) + " bytes of partial images (" +
+                                                   std::to_string(n_chunks) + " sample chunks), the static workspace holds " +
+                                                   std::to_string(NOALLOC_PARTIAL_BYTES) + "; use rrt_render_device");
+        d_counters = reinterpret_cast<unsigned long long*>(c->d_static);
+        d_partial = reinterpret_cast<float*>(c->d_static + NOALLOC_COUNTER_BYTES);
+    } else {
+        if (need > c->partial_bytes) {
+            // the old workspace may still be read by a render in flight on another stream
+            RRT_HIP(c, hipDeviceSynchronize());
+            if (c->d_partial) (void)hipFree(c->d_partial);
+            c->d_partial = nullptr;
+            c->partial_bytes = 0;
+            RRT_HIP(c, hipMalloc((void**)&c->d_partial, need));
+            c->partial_bytes = need;
+        }
+        d_counters = c->d_counters;
+        d_partial = c->d_partial;
     }
     // tuning overrides for experiments: RRT_CHUNKS (above), RRT_NODE_SHARE (0..64)
     RenderTuning tuning;
@@ -358,17 +451,31 @@ rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32
     if (const char* e = std::getenv("RRT_LEAVE_READY")) tuning.leave_ready = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RRT_OVERLAP_ITEMS")) tuning.overlap_items = std::atoi(e) != 0 ? 1u : 0u;
     if (const char* e = std::getenv("RRT_BAND_TILES")) tuning.band_tiles = (uint32_t)std::max(0, std::atoi(e));
-    RRT_HIP(c, hipMemsetAsync(c->d_counters, 0, 256, s));
+    if (rrt_status st = order_after_pending(c, s)) return st;
+    RRT_HIP(c, hipMemsetAsync(d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
-    RRT_HIP(c, launch_render(c->sdev, width, height, spp, spp_offset, d_accum, c->d_partial, n_chunks, c->d_counters,
-                             reinterpret_cast<unsigned int*>(c->d_counters + 8), c->cu_count,
+    RRT_HIP(c, launch_render(c->sdev, width, height, spp, spp_offset, d_accum, d_partial, n_chunks, d_counters,
+                             reinterpret_cast<unsigned int*>(d_counters + 8), c->cu_count,
                              (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, tuning, s));
     RRT_HIP(c, hipEventRecord(c->ev_stop, s));
     c->last_stream = s;
     c->render_pending = true;
     c->pending_samples = (uint64_t)width * height * spp;
     c->pending_rays = 0;
+    c->last_counters = d_counters;
     return RRT_OK;
+}
+
+extern "C" {
+
+rrt_status rrt_render_device(rrt_ctx* c, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
+                             float* d_accum, void* stream) {
+    return render_impl(c, width, height, spp, spp_offset, d_accum, stream, false, "rrt_render_device");
+}
+
+rrt_status rrt_render_device_noalloc(rrt_ctx* c, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
+                                     float* d_accum, void* stream) {
+    return render_impl(c, width, height, spp, spp_offset, d_accum, stream, true, "rrt_render_device_noalloc");
 }
 
 rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
@@ -377,7 +484,7 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     RRT_HIP(c, hipEventSynchronize(c->ev_stop));
     unsigned long long h[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8..11] are the work-queue heads
-    RRT_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    RRT_HIP(c, hipMemcpy(h, c->last_counters ? c->last_counters : c->d_counters, sizeof h, hipMemcpyDeviceToHost));
     float ms = 0.f;
     RRT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
     std::memset(stats, 0, sizeof *stats);
@@ -402,18 +509,15 @@ rrt_status rrt_render(rrt_ctx* c, uint32_t width, uint32_t height, uint32_t spp,
     if (width == 0 || height == 0) return set_err(c, RRT_ERR_INVALID, "rrt_render: width and height must be > 0");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     const size_t bytes = (size_t)width * height * 3 * sizeof(float);
-    float* d_accum = nullptr;
-    RRT_HIP(c, hipMalloc((void**)&d_accum, bytes));
-    rrt_status st = rrt_render_device(c, width, height, spp, spp_offset, d_accum, nullptr);
+    void* d_accum = nullptr;
+    rrt_status st = stage(c, 0, bytes, &d_accum);
+    if (st != RRT_OK) return st;
+    if ((st = rrt_render_device(c, width, height, spp, spp_offset, (float*)d_accum, nullptr)) != RRT_OK) return st;
     rrt_stats local;
-    if (st == RRT_OK) st = rrt_render_stats(c, &local);
-    if (st == RRT_OK) {
-        hipError_t e = hipMemcpy(accum, d_accum, bytes, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) st = hip_fail(c, e, "rrt_render: copy back");
-    }
-    (void)hipFree(d_accum);
-    if (st == RRT_OK && stats) *stats = local;
-    return st;
+    if ((st = rrt_render_stats(c, &local)) != RRT_OK) return st;
+    RRT_HIP(c, hipMemcpy(accum, d_accum, bytes, hipMemcpyDeviceToHost));
+    if (stats) *stats = local;
+    return RRT_OK;
 }
 
 rrt_status rrt_tonemap_device(rrt_ctx* c, const float* d_accum, uint32_t width, uint32_t height, uint32_t spp_total,
@@ -434,19 +538,14 @@ rrt_status rrt_tonemap(rrt_ctx* c, const float* accum, uint32_t width, uint32_t 
     if (width == 0 || height == 0) return set_err(c, RRT_ERR_INVALID, "rrt_tonemap: width and height must be > 0");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     const size_t n = (size_t)width * height * 3;
-    float* d_accum = nullptr;
-    uint8_t* d_rgb = nullptr;
-    hipError_t e = hipMalloc((void**)&d_accum, n * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_rgb, n);
-    if (e == hipSuccess) e = hipMemcpy(d_accum, accum, n * sizeof(float), hipMemcpyHostToDevice);
-    rrt_status st = RRT_OK;
-    if (e == hipSuccess) st = rrt_tonemap_device(c, d_accum, width, height, spp_total, d_rgb, nullptr);
-    if (e == hipSuccess && st == RRT_OK) e = hipDeviceSynchronize();
-    if (e == hipSuccess && st == RRT_OK) e = hipMemcpy(rgb8, d_rgb, n, hipMemcpyDeviceToHost);
-    if (d_accum) (void)hipFree(d_accum);
-    if (d_rgb) (void)hipFree(d_rgb);
-    if (e != hipSuccess) return hip_fail(c, e, "rrt_tonemap");
-    return st;
+    void *d_accum = nullptr, *d_rgb = nullptr;
+    rrt_status st;
+    if ((st = stage(c, 0, n * sizeof(float), &d_accum)) != RRT_OK || (st = stage(c, 1, n, &d_rgb)) != RRT_OK) return st;
+    RRT_HIP(c, hipMemcpy(d_accum, accum, n * sizeof(float), hipMemcpyHostToDevice));
+    if ((st = rrt_tonemap_device(c, (const float*)d_accum, width, height, spp_total, (uint8_t*)d_rgb, nullptr)) != RRT_OK) return st;
+    RRT_HIP(c, hipStreamSynchronize(nullptr));
+    RRT_HIP(c, hipMemcpy(rgb8, d_rgb, n, hipMemcpyDeviceToHost));
+    return RRT_OK;
 }
 
 rrt_status rrt_selftest_arith(rrt_ctx* c, uint64_t* recip_mismatches, uint64_t* sqrt_mismatches) {
@@ -464,6 +563,288 @@ rrt_status rrt_selftest_arith(rrt_ctx* c, uint64_t* recip_mismatches, uint64_t* 
     if (e != hipSuccess) return hip_fail(c, e, "rrt_selftest_arith");
     *recip_mismatches = bad[0];
     *sqrt_mismatches = bad[1];
+    return RRT_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-GPU group: one host process, one context and one stream per GPU.  Replaces the reference's only form of
+// parallelism, the rayon row pool (src/main.rs:42-49,86), across GPUs: every sample is independent (src/main.rs:91),
+// so member g renders a contiguous slice of the sample indices of every pixel and the f32 accumulation buffers are
+// summed on member 0 -- one RCCL ncclReduce over xGMI when the members sit on distinct GPUs (librccl is opened at run
+// time, only then), or a copy to member 0's GPU plus an add kernel otherwise (members sharing a GPU, RCCL absent,
+// RRT_GROUP_NO_RCCL set).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.ok ? &api : nullptr;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) return nullptr;
+    api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(api.handle, "ncclCommInitAll"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+    api.Reduce = reinterpret_cast<decltype(api.Reduce)>(dlsym(api.handle, "ncclReduce"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.handle, "ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.handle, "ncclGroupEnd"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+    api.ok = api.CommInitAll && api.CommDestroy && api.Reduce && api.GroupStart && api.GroupEnd && api.GetErrorString;
+    return api.ok ? &api : nullptr;
+}
+
+}  // namespace
+
+struct rrt_group {
+    std::vector<rrt_ctx*> members;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;       // per member: its render (and, for RCCL, its part of the reduce) is complete
+    std::vector<float*> d_accum;        // per member: accumulation buffer on its GPU (grown on demand)
+    float* d_recv = nullptr;            // on member 0's GPU: landing buffer of the copy-and-add reduce
+    size_t accum_bytes = 0;
+    std::vector<ncclComm_t> comms;      // one per member when the reduce goes through RCCL, else empty
+    std::string err;
+    std::string reduce_path;            // "none" (one member), "rccl" or "copy+add"
+};
+
+namespace {
+
+rrt_status group_err(rrt_group* g, rrt_status st, const std::string& msg) {
+    if (g) g->err = msg;
+    else g_thread_error = msg;
+    return st;
+}
+rrt_status group_member_err(rrt_group* g, size_t i, rrt_status st) {
+    return group_err(g, st, "member " + std::to_string(i) + " (device " + std::to_string(g->members[i]->cfg.device) + "): " + g->members[i]->err);
+}
+#define RRT_GHIP(g, call)                                                                                        \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess)                                                                                    \
+            return group_err(g, e_ == hipErrorOutOfMemory ? RRT_ERR_OOM : RRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+rrt_status rrt_group_create(const rrt_config* cfg, const int32_t* devices, uint32_t n_devices, rrt_group** out) {
+    if (!cfg || !devices || !out) return group_err(nullptr, RRT_ERR_INVALID, "rrt_group_create: NULL argument");
+    *out = nullptr;
+    if (n_devices == 0 || n_devices > 64u) return group_err(nullptr, RRT_ERR_INVALID, "rrt_group_create: 1..64 devices");
+    std::unique_ptr<rrt_group> g(new (std::nothrow) rrt_group());
+    if (!g) return group_err(nullptr, RRT_ERR_OOM, "rrt_group_create: out of host memory");
+    auto fail = [&](rrt_status st, const std::string& msg) {
+        rrt_group_destroy(g.release());
+        return group_err(nullptr, st, msg);
+    };
+    bool distinct = true;
+    for (uint32_t i = 0; i < n_devices; ++i) {
+        for (uint32_t j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+        rrt_config member_cfg = *cfg;
+        member_cfg.device = devices[i];
+        rrt_ctx* c = nullptr;
+        const rrt_status st = rrt_create(&member_cfg, &c);
+        if (st != RRT_OK) return fail(st, "rrt_group_create: device " + std::to_string(devices[i]) + ": " + g_thread_error);
+        g->members.push_back(c);
+        hipStream_t s = nullptr;
+        hipEvent_t ev = nullptr;
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        g->streams.push_back(s);
+        g->done.push_back(ev);
+        g->d_accum.push_back(nullptr);
+        if (e != hipSuccess) return fail(RRT_ERR_HIP, std::string("rrt_group_create: ") + hipGetErrorString(e));
+    }
+    g->reduce_path = n_devices == 1u ? "none" : "copy+add";
+    if (n_devices > 1u && distinct && !std::getenv("RRT_GROUP_NO_RCCL")) {
+        if (RcclApi* api = rccl_api()) {
+            g->comms.resize(n_devices);
+            std::vector<int> devs(devices, devices + n_devices);
+            const ncclResult_t r = api->CommInitAll(g->comms.data(), (int)n_devices, devs.data());
+            if (r != ncclSuccess) {
+                g->comms.clear();
+                return fail(RRT_ERR_HIP, std::string("rrt_group_create: ncclCommInitAll: ") + api->GetErrorString(r));
+            }
+            g->reduce_path = "rccl";
+        }
+    }
+    *out = g.release();
+    return RRT_OK;
+}
+
+void rrt_group_destroy(rrt_group* g) {
+    if (!g) return;
+    if (!g->comms.empty())
+        if (RcclApi* api = rccl_api())
+            for (ncclComm_t cm : g->comms) if (cm) (void)api->CommDestroy(cm);
+    for (size_t i = 0; i < g->members.size(); ++i) {
+        (void)hipSetDevice(g->members[i]->cfg.device);
+        if (i < g->streams.size() && g->streams[i]) { (void)hipStreamSynchronize(g->streams[i]); (void)hipStreamDestroy(g->streams[i]); }
+        if (i < g->done.size() && g->done[i]) (void)hipEventDestroy(g->done[i]);
+        if (i < g->d_accum.size() && g->d_accum[i]) (void)hipFree(g->d_accum[i]);
+        if (i == 0 && g->d_recv) (void)hipFree(g->d_recv);
+        rrt_destroy(g->members[i]);
+    }
+    delete g;
+}
+
+const char* rrt_group_last_error(const rrt_group* g) { return g ? g->err.c_str() : g_thread_error.c_str(); }
+
+uint32_t rrt_group_size(const rrt_group* g) { return g ? (uint32_t)g->members.size() : 0u; }
+
+const char* rrt_group_reduce_path(const rrt_group* g) { return g ? g->reduce_path.c_str() : ""; }
+
+rrt_status rrt_group_scene_upload(rrt_group* g, const rrt_scene_desc* scene) {
+    if (!g) return group_err(nullptr, RRT_ERR_INVALID, "rrt_group_scene_upload: group is NULL");
+    if (!scene) return group_err(g, RRT_ERR_INVALID, "rrt_group_scene_upload: scene is NULL");
+    // the host BVH is built once and uploaded to every member (with the GPU builder every member builds its own)
+    HostScene hs;
+    const bool share = (g->members[0]->cfg.flags & RRT_CFG_DEVICE_BUILD) == 0u;
+    float build_ms = 0.f;
+    if (share) {
+        std::string err;
+        rrt_status st;
+        const auto t0 = std::chrono::steady_clock::now();
+        try {
+            st = build_host_scene(scene, hs, err, build_threads(), 0u);
+        } catch (const std::bad_alloc&) {
+            return group_err(g, RRT_ERR_OOM, "rrt_group_scene_upload: out of host memory while building the BVH");
+        } catch (const std::exception& ex) {
+            return group_err(g, RRT_ERR_INVALID, std::string("rrt_group_scene_upload: ") + ex.what());
+        }
+        if (st != RRT_OK) return group_err(g, st, "rrt_group_scene_upload: " + err);
+        build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    for (size_t i = 0; i < g->members.size(); ++i) {
+        const rrt_status st = scene_upload_impl(g->members[i], scene, share ? &hs : nullptr);
+        if (st != RRT_OK) return group_member_err(g, i, st);
+        if (share) g->members[i]->info.build_ms = build_ms;
+    }
+    return RRT_OK;
+}
+
+rrt_status rrt_group_scene_get_info(const rrt_group* g, rrt_scene_info* out) {
+    if (!g || !out) return group_err(nullptr, RRT_ERR_INVALID, "rrt_group_scene_get_info: NULL argument");
+    const rrt_status st = rrt_scene_get_info(g->members[0], out);
+    if (st != RRT_OK) return group_member_err(const_cast<rrt_group*>(g), 0, st);
+    return RRT_OK;
+}
+
+rrt_status rrt_group_render(rrt_group* g, uint32_t width, uint32_t height, uint32_t spp_total, uint32_t spp_offset,
+                            float* accum, rrt_stats* stats) {
+    if (!g) return group_err(nullptr, RRT_ERR_INVALID, "rrt_group_render: group is NULL");
+    if (!accum) return group_err(g, RRT_ERR_INVALID, "rrt_group_render: accum is NULL");
+    if (width == 0 || height == 0 || spp_total == 0) return group_err(g, RRT_ERR_INVALID, "rrt_group_render: width, height and spp must be > 0");
+    if ((uint64_t)width * height > (0xFFFFFFFFull - 255ull) / 3ull) return group_err(g, RRT_ERR_INVALID, "rrt_group_render: image too large");
+    const size_t n = g->members.size();
+    const size_t n_floats = (size_t)width * height * 3u, bytes = n_floats * sizeof(float);
+    if (bytes > g->accum_bytes) {
+        for (size_t i = 0; i < n; ++i) {
+            RRT_GHIP(g, hipSetDevice(g->members[i]->cfg.device));
+            RRT_GHIP(g, hipDeviceSynchronize());
+            if (g->d_accum[i]) (void)hipFree(g->d_accum[i]);
+            g->d_accum[i] = nullptr;
+            RRT_GHIP(g, hipMalloc((void**)&g->d_accum[i], bytes));
+            if (i == 0 && n > 1 && g->comms.empty()) {
+                if (g->d_recv) (void)hipFree(g->d_recv);
+                g->d_recv = nullptr;
+                RRT_GHIP(g, hipMalloc((void**)&g->d_recv, bytes));
+            }
+        }
+        g->accum_bytes = bytes;
+    }
+    // sample slices: spp_total split evenly, the remainder to the low members; members left without samples sit out
+    std::vector<uint32_t> first(n), count(n);
+    {
+        const uint32_t base = spp_total / (uint32_t)n, rem = spp_total % (uint32_t)n;
+        uint32_t off = spp_offset;
+        for (size_t i = 0; i < n; ++i) {
+            count[i] = base + (i < rem ? 1u : 0u);
+            first[i] = off;
+            off += count[i];
+        }
+    }
+    for (size_t i = 0; i < n; ++i) {
+        rrt_ctx* c = g->members[i];
+        RRT_GHIP(g, hipSetDevice(c->cfg.device));
+        if (count[i] == 0u) {
+            RRT_GHIP(g, hipMemsetAsync(g->d_accum[i], 0, bytes, g->streams[i]));
+        } else {
+            const rrt_status st = rrt_render_device(c, width, height, count[i], first[i], g->d_accum[i], g->streams[i]);
+            if (st != RRT_OK) return group_member_err(g, i, st);
+        }
+    }
+    // the exchange step: sum of the members' buffers on member 0
+    if (n > 1 && !g->comms.empty()) {
+        RcclApi* api = rccl_api();
+        ncclResult_t r = api->GroupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; ++i)
+            r = api->Reduce(g->d_accum[i], g->d_accum[i], n_floats, ncclFloat, ncclSum, 0, g->comms[i], g->streams[i]);
+        const ncclResult_t r_end = api->GroupEnd();
+        if (r == ncclSuccess) r = r_end;
+        if (r != ncclSuccess) return group_err(g, RRT_ERR_HIP, std::string("rrt_group_render: RCCL reduce: ") + api->GetErrorString(r));
+        for (size_t i = 1; i < n; ++i) {
+            RRT_GHIP(g, hipSetDevice(g->members[i]->cfg.device));
+            RRT_GHIP(g, hipStreamSynchronize(g->streams[i]));
+        }
+    } else if (n > 1) {
+        for (size_t i = 1; i < n; ++i) {
+            RRT_GHIP(g, hipSetDevice(g->members[i]->cfg.device));
+            RRT_GHIP(g, hipEventRecord(g->done[i], g->streams[i]));
+        }
+        RRT_GHIP(g, hipSetDevice(g->members[0]->cfg.device));
+        for (size_t i = 1; i < n; ++i) {  // in member order, so that the sum is reproducible
+            RRT_GHIP(g, hipStreamWaitEvent(g->streams[0], g->done[i], 0));
+            const float* src = g->d_accum[i];
+            if (g->members[i]->cfg.device != g->members[0]->cfg.device) {
+                RRT_GHIP(g, hipMemcpyPeerAsync(g->d_recv, g->members[0]->cfg.device, g->d_accum[i], g->members[i]->cfg.device, bytes, g->streams[0]));
+                src = g->d_recv;
+            }
+            RRT_GHIP(g, launch_add(g->d_accum[0], src, n_floats, g->streams[0]));
+        }
+    }
+    RRT_GHIP(g, hipSetDevice(g->members[0]->cfg.device));
+    RRT_GHIP(g, hipMemcpyAsync(accum, g->d_accum[0], bytes, hipMemcpyDeviceToHost, g->streams[0]));
+    RRT_GHIP(g, hipStreamSynchronize(g->streams[0]));
+    rrt_stats total;
+    std::memset(&total, 0, sizeof total);
+    for (size_t i = 0; i < n; ++i) {
+        if (count[i] == 0u) continue;
+        rrt_stats st;
+        const rrt_status rs = rrt_render_stats(g->members[i], &st);
+        if (rs != RRT_OK) return group_member_err(g, i, rs);
+        total.rays += st.rays; total.samples += st.samples; total.node_visits += st.node_visits; total.prim_tests += st.prim_tests;
+        total.node_wave_steps += st.node_wave_steps; total.prim_wave_steps += st.prim_wave_steps;
+        total.shade_wave_passes += st.shade_wave_passes;
+        total.node_slots_lane_done += st.node_slots_lane_done; total.node_slots_lane_at_leaf += st.node_slots_lane_at_leaf;
+        total.kernel_ms = std::max(total.kernel_ms, st.kernel_ms);  // the members render side by side
+    }
+    if (stats) *stats = total;
+    return RRT_OK;
+}
+
+rrt_status rrt_group_tonemap(rrt_group* g, const float* accum, uint32_t width, uint32_t height, uint32_t spp_total, uint8_t* rgb8) {
+    if (!g) return group_err(nullptr, RRT_ERR_INVALID, "rrt_group_tonemap: group is NULL");
+    const rrt_status st = rrt_tonemap(g->members[0], accum, width, height, spp_total, rgb8);
+    if (st != RRT_OK) return group_member_err(g, 0, st);
     return RRT_OK;
 }
 

@@ -116,13 +116,16 @@ __host__ __device__ __forceinline__ uint32_t rng_u32(Rng& r) {
 }
 // rand 0.8 `Standard` for f32: 24 random bits scaled into [0, 1)
 __device__ __forceinline__ float rng_f32(Rng& r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
-// rand 0.8 `gen_range(lo..hi)` for f32 (UniformFloat::sample_single): 23 bits into [1,2), minus 1, scale, offset
+// rand 0.8 `gen_range(lo..hi)` for f32 (UniformFloat::sample_single): 23 bits into [1,2), minus 1, times scale, plus lo;
+// a result rounded up to hi is drawn again with scale one ulp smaller.  rand's loop has no bound; this one gives up
+// after 8 draws (with the decreasing scale a second failure needs the largest of the 2^23 values twice in a row).
 __device__ __forceinline__ float rng_range(Rng& r, float lo, float hi) {
-    const float scale = hi - lo;
+    float scale = hi - lo;
     for (int tries = 0; tries < 8; ++tries) {
         float v12 = __uint_as_float((rng_u32(r) >> 9) | 0x3f800000U);
         float res = (v12 - 1.0f) * scale + lo;
         if (res < hi) return res;
+        scale = __uint_as_float(__float_as_uint(scale) - 1u);
     }
     return lo;
 }

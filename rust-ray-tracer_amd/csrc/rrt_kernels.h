@@ -56,6 +56,9 @@ hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, 
 hipError_t launch_tonemap(const float* d_accum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_rgb8,
                           hipStream_t stream);
 
+// d_dst[i] += d_src[i] for n floats (both 16-byte aligned).
+hipError_t launch_add(float* d_dst, const float* d_src, size_t n, hipStream_t stream);
+
 // d_bad: 2 x u64, zero before the launch; receives the number of float bit patterns (of all 2^32) on which the
 // kernels' short reciprocal / square root differ from the IEEE operations.
 hipError_t launch_check_arith(unsigned long long* d_bad, hipStream_t stream);

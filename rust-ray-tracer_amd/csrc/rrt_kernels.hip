@@ -565,6 +565,20 @@ __global__ void k_reduce_chunks(const float* __restrict__ partial, uint32_t n_fl
     accum[i] = s;
 }
 
+// dst[i] += src[i]: the sum step of a multi-GPU group whose members' accumulation buffers are gathered on one GPU.
+__global__ void k_add(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n4 = n / 4u;
+    if (i < n4) {
+        float4 a = reinterpret_cast<float4*>(dst)[i];
+        const float4 b = reinterpret_cast<const float4*>(src)[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        reinterpret_cast<float4*>(dst)[i] = a;
+    } else if (i == n4) {
+        for (size_t k = n4 * 4u; k < n; ++k) dst[k] += src[k];
+    }
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 
 uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t samples_per_item) {
@@ -684,6 +698,13 @@ hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, 
     if (inst) return launch_trace_variant<true, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
     if (count_visits) return launch_trace_variant<false, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
     return launch_trace_variant<false, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+}
+
+hipError_t launch_add(float* d_dst, const float* d_src, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const size_t threads = n / 4u + 1u;
+    hipLaunchKernelGGL(k_add, dim3((unsigned)((threads + 255u) / 256u)), dim3(256), 0, stream, d_dst, d_src, n);
+    return hipGetLastError();
 }
 
 hipError_t launch_check_arith(unsigned long long* d_bad, hipStream_t stream) {

@@ -96,10 +96,23 @@ double need_num(const Value& o, const char* key, const std::string& where) {
     if (!v.is_number()) fail(RRT_ERR_PARSE, "field `" + std::string(key) + "` in " + where + " is not a number");
     return v.num;
 }
+// Indices, counts and byte offsets a file supplies: non-negative integers below 2^40 (far beyond any real file, and small
+// enough that sums and products of a few of them cannot wrap a size_t).
+constexpr double INDEX_LIMIT = 1099511627776.0;
+constexpr size_t NO_INDEX = (size_t)-1;
+// The value as an index, or NO_INDEX (which no container size exceeds) if it is not a number of that kind.
+size_t as_index(const Value& v) {
+    if (!v.is_number() || !(v.num >= 0.0) || !(v.num < INDEX_LIMIT) || v.num != std::floor(v.num)) return NO_INDEX;
+    return (size_t)v.num;
+}
 size_t need_index(const Value& o, const char* key, const std::string& where) {
-    double d = need_num(o, key, where);
-    if (d < 0 || d != std::floor(d)) fail(RRT_ERR_PARSE, "field `" + std::string(key) + "` in " + where + " is not a non-negative integer");
-    return (size_t)d;
+    const size_t i = as_index(need(o, key, where));
+    if (i == NO_INDEX) fail(RRT_ERR_PARSE, "field `" + std::string(key) + "` in " + where + " is not a non-negative integer below 2^40");
+    return i;
+}
+// An optional index-valued field: `absent` if the field is missing, an error if it is present and malformed.
+size_t opt_index(const Value& o, const char* key, const std::string& where, size_t absent) {
+    return o.get(key) ? need_index(o, key, where) : absent;
 }
 const std::string& need_str(const Value& o, const char* key, const std::string& where) {
     const Value& v = need(o, key, where);
@@ -238,8 +251,8 @@ NodeResult handle_node(const Value& root, const Value& nodes, size_t index, int 
     const Value& node = nodes.at(index);
     if (const Value* cam_ref = node.get("camera")) {
         const Value* cams = root.get("cameras");
-        if (cams && cams->is_array() && cam_ref->is_number() && (size_t)cam_ref->num < cams->size()) {
-            const Value& cam = cams->at((size_t)cam_ref->num);
+        if (cams && cams->is_array() && cam_ref->is_number() && as_index(*cam_ref) < cams->size()) {
+            const Value& cam = cams->at(as_index(*cam_ref));
             const Value* persp = cam.get("perspective");
             const Value* type = cam.get("type");
             if (persp && type && type->is_string() && type->str == "perspective") {
@@ -260,8 +273,8 @@ NodeResult handle_node(const Value& root, const Value& nodes, size_t index, int 
         const Value* rext = root.get("extensions");
         const Value* rkl = rext ? rext->get("KHR_lights_punctual") : nullptr;
         const Value* lights = rkl ? rkl->get("lights") : nullptr;
-        if (li && li->is_number() && lights && lights->is_array() && (size_t)li->num < lights->size()) {
-            const Value& light = lights->at((size_t)li->num);
+        if (li && li->is_number() && lights && lights->is_array() && as_index(*li) < lights->size()) {
+            const Value& light = lights->at(as_index(*li));
             float color[3] = {1.f, 1.f, 1.f};
             float intensity = 1.f;
             if (const Value* c = light.get("color")) if (c->is_array() && c->size() == 3) for (int i = 0; i < 3; ++i) color[i] = (float)c->at(i).num;
@@ -277,7 +290,7 @@ NodeResult handle_node(const Value& root, const Value& nodes, size_t index, int 
     }
     const Value* children = node.get("children");
     if (children && children->is_array() && children->size() == 1 && children->at(0).is_number()) {
-        NodeResult child = handle_node(root, nodes, (size_t)children->at(0).num, depth + 1);
+        NodeResult child = handle_node(root, nodes, as_index(children->at(0)), depth + 1);
         if (child.kind != 0) {
             const Affine a = affine_from(node_matrix(node));
             if (child.kind == 1) camera_apply(child.cam, a);
@@ -297,7 +310,7 @@ void collect_camera_lights(const Value& root, rrt_camera& camera, std::vector<No
         if (!roots || !roots->is_array()) continue;
         for (size_t ni = 0; ni < roots->size(); ++ni) {
             if (!roots->at(ni).is_number()) continue;
-            NodeResult r = handle_node(root, *nodes, (size_t)roots->at(ni).num, 0);
+            NodeResult r = handle_node(root, *nodes, as_index(roots->at(ni)), 0);
             if (r.kind == 1) camera = r.cam;
             else if (r.kind == 2) lights.push_back(r);
         }
@@ -358,7 +371,7 @@ void load_compat(const Value& root, OwnedScene& sc) {
         size_t b = need_index(views.at(i), "buffer", where);
         size_t len = need_index(views.at(i), "byteLength", where);
         size_t off = need_index(views.at(i), "byteOffset", where);
-        if (b >= buf_bytes.size() || off + len > buf_bytes[b].size()) fail(RRT_ERR_PARSE, where + " exceeds its buffer");
+        if (b >= buf_bytes.size() || off > buf_bytes[b].size() || len > buf_bytes[b].size() - off) fail(RRT_ERR_PARSE, where + " exceeds its buffer");
         view_bytes.emplace_back(buf_bytes[b].begin() + (long)off, buf_bytes[b].begin() + (long)(off + len));
     }
     for (size_t i = 0; i < materials.size(); ++i) {
@@ -386,7 +399,7 @@ void load_compat(const Value& root, OwnedScene& sc) {
         a.type = need_str(accessors.at(i), "type", where);
         if (a.view >= view_bytes.size()) fail(RRT_ERR_PARSE, where + ".bufferView out of range");
         size_t elem = a.type == "VEC3" ? 12 : a.type == "VEC2" ? 8 : a.type == "SCALAR" ? 2 : 0;
-        if (elem * a.count > view_bytes[a.view].size()) fail(RRT_ERR_PARSE, where + " reads past its buffer view");
+        if (elem != 0 && a.count > view_bytes[a.view].size() / elem) fail(RRT_ERR_PARSE, where + " reads past its buffer view");
         accs.push_back(a);
     }
     for (size_t mi = 0; mi < meshes.size(); ++mi) {
@@ -484,17 +497,19 @@ void load_extended(const Value& root, const std::string& path, const rrt_gltf_op
         if (ai >= accessors->size()) fail(RRT_ERR_PARSE, "accessor index out of range");
         const Value& a = accessors->at(ai);
         const Value* bv = a.get("bufferView");
-        if (!bv || !bv->is_number() || (size_t)bv->num >= views->size()) fail(RRT_ERR_PARSE, "accessor without a valid bufferView");
-        const Value& view = views->at((size_t)bv->num);
+        if (!bv || !bv->is_number() || as_index(*bv) >= views->size()) fail(RRT_ERR_PARSE, "accessor without a valid bufferView");
+        const Value& view = views->at(as_index(*bv));
         size_t b = need_index(view, "buffer", "bufferViews[]");
-        size_t voff = view.get("byteOffset") ? (size_t)view.get("byteOffset")->num : 0;
+        size_t voff = opt_index(view, "byteOffset", "bufferViews[]", 0);
         size_t vlen = need_index(view, "byteLength", "bufferViews[]");
-        size_t aoff = a.get("byteOffset") ? (size_t)a.get("byteOffset")->num : 0;
-        stride = view.get("byteStride") ? (size_t)view.get("byteStride")->num : 0;
+        size_t aoff = opt_index(a, "byteOffset", "accessors[]", 0);
+        stride = opt_index(view, "byteStride", "bufferViews[]", 0);
         if (stride == 0) stride = elem_bytes;
         count = need_index(a, "count", "accessors[]");
         if (b >= buf_bytes.size()) fail(RRT_ERR_PARSE, "bufferView buffer index out of range");
-        if (count && (aoff + (count - 1) * stride + elem_bytes > vlen || voff + vlen > buf_bytes[b].size())) fail(RRT_ERR_PARSE, "accessor reads past its buffer");
+        // by subtraction and division, so that no sum or product of file-supplied values can wrap
+        if (voff > buf_bytes[b].size() || vlen > buf_bytes[b].size() - voff) fail(RRT_ERR_PARSE, "bufferView exceeds its buffer");
+        if (count && (aoff > vlen || elem_bytes > vlen - aoff || (count - 1) > (vlen - aoff - elem_bytes) / stride)) fail(RRT_ERR_PARSE, "accessor reads past its buffer view");
         base = buf_bytes[b].data() + voff + aoff;
     };
 
@@ -503,17 +518,18 @@ void load_extended(const Value& root, const std::string& path, const rrt_gltf_op
         const Value& node = nodes->at(ni);
         const Mat4 world = mat_mul(parent, node_matrix(node));
         if (const Value* mref = node.get("mesh")) {
-            if (mref->is_number() && (size_t)mref->num < meshes->size()) {
-                const Value* prims = meshes->at((size_t)mref->num).get("primitives");
+            if (mref->is_number() && as_index(*mref) < meshes->size()) {
+                const Value* prims = meshes->at(as_index(*mref)).get("primitives");
                 for (size_t pi = 0; prims && pi < prims->size(); ++pi) {
                     const Value& prim = prims->at(pi);
-                    if (const Value* mode = prim.get("mode")) if (mode->is_number() && (int)mode->num != 4) continue;
+                    if (const Value* mode = prim.get("mode")) if (as_index(*mode) != 4) continue;
                     const Value* attrs = prim.get("attributes");
                     const Value* posa = attrs ? attrs->get("POSITION") : nullptr;
                     if (!posa || !posa->is_number()) continue;
-                    if (accessors->at((size_t)posa->num).get("type") && accessors->at((size_t)posa->num).get("type")->str != "VEC3") continue;
+                    if (as_index(*posa) >= accessors->size()) fail(RRT_ERR_PARSE, "POSITION accessor index out of range");
+                    if (const Value* ty = accessors->at(as_index(*posa)).get("type")) if (!ty->is_string() || ty->str != "VEC3") continue;
                     const uint8_t* pbase; size_t pstride, pcount;
-                    accessor_span((size_t)posa->num, 12, pbase, pstride, pcount);
+                    accessor_span(as_index(*posa), 12, pbase, pstride, pcount);
                     std::vector<float> pos(3 * pcount);
                     for (size_t i = 0; i < pcount; ++i) {
                         float p[3];
@@ -525,11 +541,12 @@ void load_extended(const Value& root, const std::string& path, const rrt_gltf_op
                     }
                     std::vector<uint32_t> idx;
                     if (const Value* ia = prim.get("indices")) {
-                        const Value& acc = accessors->at((size_t)ia->num);
-                        int ct = acc.get("componentType") ? (int)acc.get("componentType")->num : 5123;
+                        if (as_index(*ia) >= accessors->size()) fail(RRT_ERR_PARSE, "indices accessor index out of range");
+                        const Value& acc = accessors->at(as_index(*ia));
+                        const size_t ct = opt_index(acc, "componentType", "accessors[]", 5123);
                         size_t eb = ct == 5121 ? 1 : ct == 5125 ? 4 : 2;
                         const uint8_t* ibase; size_t istride, icount;
-                        accessor_span((size_t)ia->num, eb, ibase, istride, icount);
+                        accessor_span(as_index(*ia), eb, ibase, istride, icount);
                         idx.resize(icount);
                         for (size_t i = 0; i < icount; ++i) {
                             const uint8_t* q = ibase + i * istride;
@@ -540,7 +557,7 @@ void load_extended(const Value& root, const std::string& path, const rrt_gltf_op
                         for (size_t i = 0; i < pcount; ++i) idx[i] = (uint32_t)i;
                     }
                     uint32_t mat = 0;
-                    if (const Value* mv = prim.get("material")) if (mv->is_number() && (size_t)mv->num < sc.materials.size()) mat = (uint32_t)mv->num;
+                    if (const Value* mv = prim.get("material")) if (mv->is_number() && as_index(*mv) < sc.materials.size()) mat = (uint32_t)mv->num;
                     for (size_t t = 0; t + 2 < idx.size(); t += 3) {
                         if (idx[t] >= pcount || idx[t + 1] >= pcount || idx[t + 2] >= pcount) fail(RRT_ERR_PARSE, "vertex index out of range");
                         rrt_triangle tri;
@@ -553,14 +570,14 @@ void load_extended(const Value& root, const std::string& path, const rrt_gltf_op
         }
         if (const Value* ch = node.get("children"))
             for (size_t i = 0; ch->is_array() && i < ch->size(); ++i)
-                if (ch->at(i).is_number()) visit((size_t)ch->at(i).num, world, depth + 1);
+                if (ch->at(i).is_number()) visit(as_index(ch->at(i)), world, depth + 1);
     };
     const Value* scenes = root.get("scenes");
-    size_t scene_index = root.get("scene") && root.get("scene")->is_number() ? (size_t)root.get("scene")->num : 0;
+    size_t scene_index = root.get("scene") && root.get("scene")->is_number() ? as_index(*root.get("scene")) : 0;
     if (scenes && scenes->is_array() && scene_index < scenes->size()) {
         const Value* roots = scenes->at(scene_index).get("nodes");
         for (size_t i = 0; roots && roots->is_array() && i < roots->size(); ++i)
-            if (roots->at(i).is_number()) visit((size_t)roots->at(i).num, mat_identity(), 0);
+            if (roots->at(i).is_number()) visit(as_index(roots->at(i)), mat_identity(), 0);
     }
 }
 

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <map>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -33,7 +34,11 @@ struct Value {
     bool is_object() const { return type == Object; }
     bool is_bool() const { return type == Bool; }
     size_t size() const { return type == Array ? arr.size() : 0; }
-    const Value& at(size_t i) const { return *arr[i]; }
+    // bounds-checked: indices often come straight from the file being read
+    const Value& at(size_t i) const {
+        if (type != Array || i >= arr.size() || !arr[i]) throw std::out_of_range("JSON array index out of range");
+        return *arr[i];
+    }
 };
 
 class Parser {

@@ -291,11 +291,22 @@ def synthetic_flattened(rrt, assets_dir: str, n_lat: int = 250, n_lon: int = 251
     return s
 
 
-def metal_rough_spheres(rrt, assets_dir: str, scale: float = 3000.0):
+GLASS_EVERY = 7  # material sidecar of metal_rough_spheres: materials 3, 10, 17, ... (14 of the 98) become glass
+
+
+def metal_rough_spheres(rrt, assets_dir: str, scale: float = 3000.0, dielectric: bool = False):
     """assets/MetalRoughSpheres through the extended loader (external .bin, accessor byteOffset, node translations
-    baked, uniform scale), lit by one emissive sphere, viewed by a camera of its own."""
+    baked, uniform scale), lit by one emissive sphere, viewed by a camera of its own.
+
+    The file has no glass: the reference's glTF route maps a material to Lambertian or Metal only
+    (``src/gltf.rs:147-168``).  ``dielectric=True`` applies a material sidecar on top of the loaded scene: every
+    material whose index is 3 modulo GLASS_EVERY (one sphere per row of seven) becomes ``Dielectric(1.5)``
+    (``src/material/mod.rs:110-148``), so that all four material kinds run on the million-triangle scene."""
     path = os.path.join(assets_dir, "MetalRoughSpheres", "MetalRoughSpheres.gltf")
     s = rrt.Scene.from_gltf_file(path, path, extended=True, scale=scale)
+    if dielectric:
+        for i in range(3, len(s.materials), GLASS_EVERY):
+            s.materials[i] = rrt.Dielectric(1.5)
     r = 0.00035 * scale
     lo, hi = np.array([-r, -r, -0.003 * scale - r]), np.array([0.006 * scale + r, 0.006 * scale + r, r])
     centre = (lo + hi) / 2

@@ -1,6 +1,8 @@
 """The multi-process path on CPU: world_size 2 over gloo.  Each rank renders its slice of the sample range with the
-ORACLE (standing in for the GPU kernel, which cannot run here), the accumulation buffers are reduced to rank 0 with the
-same `dist.reduce_accum` the benchmark uses, and the result must equal the single-process image of the whole range."""
+ORACLE (standing in for the GPU kernel, which cannot run here); the slice arithmetic (`dist.rank_slice`) and the sum on
+rank 0 (`dist.reduce_accum`, `dist.all_reduce_value`) are the functions bench.py imports and calls, and the result must
+equal the single-process image of the whole range.  (The same path with the HIP library in every rank runs on the GPU
+box: tests/test_gpu_bench.py.)"""
 import os
 import socket
 import sys
@@ -27,6 +29,15 @@ def test_spp_partition_is_disjoint_and_complete(rrt):
     assert [n for _, n in parts] == [3, 3, 2, 2] and [o for o, _ in parts] == [0, 3, 6, 8]
     with pytest.raises(ValueError):
         rdist.spp_slice(2, 2, 8)
+    # the two partitions behind one call, as the benchmark uses them
+    assert rdist.rank_slice(3, 8, 1024, "strong") == (384, 128, 1024)
+    assert rdist.rank_slice(3, 8, 128, "weak") == (384, 128, 1024)
+    assert rdist.rank_slice(0, 1, 1024, "strong") == (0, 1024, 1024)
+    assert [rdist.rank_slice(r, 3, 10, "strong")[:2] for r in range(3)] == [(0, 4), (4, 3), (7, 3)]
+    with pytest.raises(ValueError):
+        rdist.rank_slice(0, 2, 8, "sideways")
+    # outside a process group the collectives are no-ops
+    assert rdist.all_reduce_value(2.5, "max") == 2.5 and rdist.reduce_accum("untouched") == "untouched"
 
 
 def _worker(rank, world, port, out_path):
@@ -46,14 +57,15 @@ def _worker(rank, world, port, out_path):
     scene = helpers.scene_default(rrt)
     o = oracle.OracleScene(scene)
     w, h, spp = 48, 27, 3
-    off, n, total = rdist.spp_slice(rank, world, spp)
+    off, n, total = rdist.rank_slice(rank, world, spp, "weak")
     accum, rays = o.render(w, h, n, spp_offset=off, seed=4, threads=2)
     t = torch.from_numpy(accum)
-    rdist.reduce_accum(t, dst=0)
-    rays_t = torch.tensor([rays], dtype=torch.int64)
-    dist.all_reduce(rays_t)
+    rdist.reduce_accum(t, dst=0, via_host=(rank == 0))  # both forms of the call end in the same gloo reduce on CPU tensors
+    all_rays = rdist.all_reduce_value(rays, "sum")
+    slowest = rdist.all_reduce_value(float(rank), "max")
     if rank == 0:
-        np.savez(out_path, accum=t.numpy(), rays=rays_t.numpy(), total=total)
+        assert slowest == world - 1
+        np.savez(out_path, accum=t.numpy(), rays=np.array([int(all_rays)]), total=total)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -129,3 +129,82 @@ def test_writer_output_is_loadable_in_compat_mode(rrt, tmp_path):
     assert len(s.lights) == 1 and s.camera.origin[1] > 0
     d = json.load(open(p))
     assert all(a["type"] in ("VEC3", "SCALAR") for a in d["accessors"]) and all("byteOffset" in v for v in d["bufferViews"])
+
+
+def _tiny_extended_doc():
+    """One triangle, u16 indices, everything in one base64 buffer: positions at 0 (36 bytes), indices at 36 (6 bytes)."""
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32).tobytes()
+    idx = np.array([0, 1, 2], np.uint16).tobytes()
+    blob = pos + idx + b"\0\0"
+    return {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}]}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 6}],
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+    }
+
+
+def _load_extended(rrt, tmp_path, doc, name="m.gltf"):
+    p = tmp_path / name
+    p.write_text(json.dumps(doc))
+    return rrt.Scene.from_gltf_file(str(p), os.path.join(ASSETS, "suzanne.gltf"), extended=True)
+
+
+def test_extended_loader_reads_the_tiny_document(rrt, tmp_path):
+    s = _load_extended(rrt, tmp_path, _tiny_extended_doc())
+    assert s.triangle_count == 1
+    t = np.concatenate(s._tri_chunks)[0]
+    assert np.array_equal(t["v1"], (1, 0, 0)) and np.array_equal(t["v2"], (0, 1, 0))
+
+
+@pytest.mark.parametrize("mutate", [
+    lambda d: d["meshes"][0]["primitives"][0]["attributes"].__setitem__("POSITION", 7),      # accessor index out of range
+    lambda d: d["meshes"][0]["primitives"][0]["attributes"].__setitem__("POSITION", -1),
+    lambda d: d["meshes"][0]["primitives"][0].__setitem__("indices", 99),
+    lambda d: d["meshes"][0]["primitives"][0].__setitem__("indices", "one"),                # not a number
+    lambda d: d["meshes"][0]["primitives"][0].__setitem__("indices", 1e300),
+    lambda d: d["accessors"][0].__setitem__("bufferView", 5),
+    lambda d: d["accessors"][1].__setitem__("byteOffset", -2),                               # negative offsets
+    lambda d: d["bufferViews"][0].__setitem__("byteOffset", -36),
+    lambda d: d["bufferViews"][1].__setitem__("byteOffset", 2 ** 64 - 2048),                 # would wrap a size_t sum
+    lambda d: d["bufferViews"][1].__setitem__("byteLength", 2 ** 63),
+    lambda d: d["accessors"][0].__setitem__("byteOffset", 2 ** 64 - 16),
+    lambda d: d["accessors"][0].__setitem__("count", 2 ** 62),
+    lambda d: d["bufferViews"][0].__setitem__("byteStride", 2 ** 63),
+    lambda d: d["accessors"][1].__setitem__("count", 4),                                     # one index past the view
+    lambda d: d["bufferViews"][0].__setitem__("buffer", 3),
+    lambda d: d["scenes"][0].__setitem__("nodes", [0.5]),
+])
+def test_extended_loader_rejects_malformed_references(rrt, tmp_path, mutate):
+    """File-supplied indices, counts and offsets that are negative, fractional, huge or out of range are reported as
+    parse errors; none of them may reach an array access or wrap a bounds check."""
+    d = _tiny_extended_doc()
+    mutate(d)
+    try:
+        s = _load_extended(rrt, tmp_path, d)
+    except rrt.RrtError as e:
+        assert e.status == 6, e
+    else:
+        # a reference that is merely skipped (e.g. a scene root that is no node index) loads an empty mesh list
+        assert s.triangle_count == 0
+
+
+def test_compat_loader_rejects_wrapping_offsets(rrt, tmp_path):
+    d = json.load(open(os.path.join(ASSETS, "default.gltf")))
+    for view_patch in ({"byteOffset": 2 ** 64 - 2048, "byteLength": 4096}, {"byteOffset": 2 ** 40}, {"byteLength": 2 ** 39}):
+        e2 = json.loads(json.dumps(d))
+        e2["bufferViews"][0].update(view_patch)
+        p = tmp_path / "wrap.gltf"
+        p.write_text(json.dumps(e2))
+        with pytest.raises(rrt.RrtError) as e:
+            rrt.Scene.from_gltf_file(str(p), os.path.join(ASSETS, "suzanne.gltf"))
+        assert e.value.status == 6
+    e3 = json.loads(json.dumps(d))
+    e3["accessors"][0]["count"] = 2 ** 39
+    p = tmp_path / "count.gltf"
+    p.write_text(json.dumps(e3))
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.Scene.from_gltf_file(str(p), os.path.join(ASSETS, "suzanne.gltf"))
+    assert e.value.status == 6

@@ -60,3 +60,21 @@ def test_cli_extended_loader(tmp_path):
     # without --extended the external .bin is rejected, as the reference would fail on it (gltf.rs:123)
     p = run_cli(["-g", "assets/MetalRoughSpheres/MetalRoughSpheres.gltf", "-o", out, "36", "2"])
     assert p.returncode != 0
+
+
+def test_cli_gpus_flag_splits_the_samples_over_group_members(rrt, tmp_path):
+    """--gpus N / --devices LIST: one process, one context per listed device, the sample range split over them and
+    summed on the first.  The box has one GPU, so the list repeats device 0 (a rehearsal of the partition)."""
+    a, b = str(tmp_path / "one.png"), str(tmp_path / "two.png")
+    p1 = run_cli(["-o", a, "--seed", "5", "--stats", "40", "8"])
+    p2 = run_cli(["-o", b, "--seed", "5", "--stats", "--devices", "0,0", "40", "8"])
+    assert p1.returncode == 0 and p2.returncode == 0, p2.stderr
+    s1, s2 = (json.loads(p.stdout.strip().splitlines()[-1]) for p in (p1, p2))
+    assert s2["gpus"] == 2 and s2["reduce"] == "copy+add" and s1["gpus"] == 1
+    assert s1["rays"] == s2["rays"] and s1["samples"] == s2["samples"]
+    i1, i2 = decode_png(open(a, "rb").read()).astype(int), decode_png(open(b, "rb").read()).astype(int)
+    assert np.abs(i1 - i2).max() <= 1  # same samples, summed in another order
+    p = run_cli(["--gpus", "1", "-o", b, "--seed", "5", "--stats", "40", "8"])
+    assert p.returncode == 0 and np.array_equal(decode_png(open(b, "rb").read()), i1)
+    p = run_cli(["--gpus", "9", "-o", b, "16", "1"])  # more GPUs than the box has
+    assert p.returncode != 0 and "device" in p.stderr

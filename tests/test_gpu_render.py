@@ -5,7 +5,9 @@ tightly than "statistically" (measured: relative L1 of 3e-8 to 1e-7, apart from 
 triangle, about one pixel in a thousand).  The remaining differences come from libm vs the device's polynomial
 sin/cos, from the 1-ulp hardware reciprocal / reciprocal square root the device uses for normalisations and the final
 path weight, and from the throughput form of the estimator.  Stated tolerances:
-  * same seed:        relative L1 <= 2e-3 of the oracle image, mean luminance within 1e-3 relative, ray counts within 0.1 %
+  * same seed:        at least 99.8 % of the pixels within 1e-4 relative (1e-5 absolute), relative L1 over those pixels
+                      <= 1e-5; over the whole image (the few pixels whose path met another triangle included)
+                      relative L1 <= 2e-3 and mean luminance within 1e-3 relative; ray counts within 0.1 %
   * different seeds:  mean luminance within 3 sigma of the estimated Monte-Carlo noise, RMSE of the tone-mapped image
                       against the oracle no larger than 1.25 x the RMSE between two oracle renders with different seeds
 """
@@ -40,11 +42,16 @@ def test_same_seed_image_matches_the_oracle(rrt, oracle, name, w, h, spp):
     finite = np.isfinite(ref) & np.isfinite(accum)
     assert finite.mean() > 0.999
     a, b = np.where(finite, accum, 0), np.where(finite, ref, 0)
+    # per-pixel: all but the rare pixel whose path met another triangle after an ulp-sized change of direction agree
+    # to float precision (measured: at most 0.1 % of the pixels differ)
+    close = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
+    assert close.mean() >= 0.998, close.mean()
+    # ... and on those pixels the images agree to 1e-5 of the image's L1 norm (measured: 3e-8 to 1e-7)
+    both = np.where(close[..., None], a, 0), np.where(close[..., None], b, 0)
+    assert rel_l1(*both) <= 1e-5, rel_l1(*both)
+    # the whole image, the few diverged paths included
     assert rel_l1(a, b) <= 2e-3, rel_l1(a, b)
     assert abs(luminance(a).mean() - luminance(b).mean()) <= 1e-3 * luminance(b).mean()
-    # per-pixel: the overwhelming majority of pixels agree to float precision
-    close = np.isclose(a, b, rtol=1e-4, atol=1e-5).all(axis=-1)
-    assert close.mean() > 0.99, close.mean()
     rgb = r.tonemap(accum, spp)
     assert np.array_equal(rgb, oracle.tonemap(accum, spp))  # get_color is bit-exact integer output
     r.close()
@@ -115,6 +122,32 @@ def test_chunked_and_unchunked_renders_agree(rrt, monkeypatch):
     auto, s3 = r.render(71, 40, 48)
     assert s1.rays == s2.rays == s3.rays
     assert np.allclose(one, many, rtol=2e-5, atol=1e-5) and np.allclose(one, auto, rtol=2e-5, atol=1e-5)
+    r.close()
+
+
+@pytest.mark.parametrize("spp,chunks", [(50, 12), (25, 6), (33, 8), (7, 7)])
+def test_sample_counts_that_do_not_fill_their_chunks(rrt, monkeypatch, spp, chunks):
+    """50 samples cut into 12 chunks are 10 chunks of 5: no chunk may be left without samples, because the pipelined
+    form of the kernel writes a partial image only for chunks that have some and the chunk sum reads them all.  The
+    workspace is dirtied first by a render that fills every chunk."""
+    r = rrt.Renderer(seed=8)
+    r.upload(helpers.scene_synthetic_small(rrt))
+    w, h = 256, 256
+    monkeypatch.setenv("RRT_CHUNKS", str(chunks))
+    monkeypatch.setenv("RRT_OVERLAP_ITEMS", "1")
+    r.render(w, h, 4 * chunks)  # every chunk of the workspace now holds another image's sums
+    piped, sp = r.render(w, h, spp)
+    monkeypatch.setenv("RRT_OVERLAP_ITEMS", "0")
+    plain, s0 = r.render(w, h, spp)
+    assert sp.rays == s0.rays and np.array_equal(piped, plain)
+    monkeypatch.setenv("RRT_CHUNKS", "1")
+    one, s1 = r.render(w, h, spp)
+    assert s1.rays == sp.rays and np.allclose(piped, one, rtol=2e-5, atol=1e-5)
+    # the default chunking of the library (whatever it picks) agrees as well
+    monkeypatch.delenv("RRT_CHUNKS")
+    monkeypatch.setenv("RRT_OVERLAP_ITEMS", "1")
+    auto, sa = r.render(w, h, spp)
+    assert sa.rays == sp.rays and np.allclose(auto, one, rtol=2e-5, atol=1e-5)
     r.close()
 
 
@@ -280,4 +313,78 @@ def test_metal_rough_spheres_asset_matches_the_oracle(rrt, oracle):
     ref, ref_rays = o.render(w, h, spp, seed=4)
     assert abs(int(st.rays) - ref_rays) <= 2
     assert rel_l1(accum, ref) <= 2e-3
+    r.close()
+
+
+def test_metal_rough_spheres_with_the_glass_sidecar(rrt, oracle):
+    """Benchmark configuration 3 as the bench runs it: the same asset with every seventh material turned into
+    Dielectric(1.5) (reference src/material/mod.rs:110-148), so that Lambertian, Metal, Dielectric and the emissive light
+    all run on the million-triangle scene.  Closest hits against the exhaustive search (the geometry is the same, the
+    check is that the sidecar changes materials only), glass really being hit, and a small same-seed image whose paths
+    refract and reflect inside the glass spheres."""
+    from rust_ray_tracer_amd import scenes
+
+    scene = scenes.metal_rough_spheres(rrt, helpers.ASSETS, dielectric=True)
+    kinds = [m[0] for m in scene.materials]
+    assert kinds.count(rrt.MAT_DIELECTRIC) == 14 and rrt.MAT_METAL in kinds and rrt.MAT_LAMBERTIAN in kinds and rrt.MAT_DIFFUSE_LIGHT in kinds
+    r = rrt.Renderer(seed=4)
+    r.upload(scene)
+    o = oracle.OracleScene(scene)
+    prim = helpers.primary_rays(o, 2560, 1440, 768, seed=31)
+    want = o.intersect(prim)
+    helpers.assert_hits_match(r.intersect(prim), want)
+    tri_mat = np.concatenate(scene._tri_chunks)["material"]
+    hit_ids = want["prim_id"][(want["prim_id"] >= 0) & (want["prim_id"] < len(tri_mat))]
+    glass_hits = np.isin(tri_mat[hit_ids] % scenes.GLASS_EVERY, [3]).sum()
+    assert glass_hits > 10  # primary rays do meet glass spheres
+    w, h, spp = 48, 27, 2
+    accum, st = r.render(w, h, spp)
+    ref, ref_rays = o.render(w, h, spp, seed=4)
+    assert abs(int(st.rays) - ref_rays) <= 2
+    close = np.isclose(accum, ref, rtol=1e-4, atol=1e-5).all(axis=-1)
+    assert close.mean() >= 0.99, close.mean()  # refraction chains amplify an ulp more often than diffuse paths do
+    assert rel_l1(accum, ref) <= 2e-3
+    # without the sidecar the image differs: the glass is really there
+    plain = rrt.Renderer(seed=4)
+    plain.upload(scenes.metal_rough_spheres(rrt, helpers.ASSETS))
+    other, _ = plain.render(w, h, spp)
+    assert not np.allclose(other, accum, rtol=1e-3)
+    plain.close()
+    r.close()
+
+
+def test_instanced_workload_at_full_size(rrt, oracle):
+    """Benchmark configuration 5 (a 100k-triangle mesh x 100 Translate(RotateY(..)) instances, reference
+    src/geometry/transform.rs:22-31,99-130) through the instanced form of the render kernel at its full 7680x4320 frame
+    and a few samples: bitwise reproducibility, sample slices that add up, ray bounds, two independent estimates that
+    agree -- and a crop-sized same-seed frame against the oracle."""
+    from rust_ray_tracer_amd import scenes
+
+    scene = scenes.synthetic_instanced(rrt, helpers.ASSETS)
+    r = rrt.Renderer(seed=1)
+    info = r.upload(scene)
+    assert info.prim_count > 10_000_000 and info.tri_count < 200_000  # instanced: ten million ids, one mesh in memory
+    w, h = 7680, 4320
+    whole, sw = r.render(w, h, 2, 0)
+    again, sa = r.render(w, h, 2, 0)
+    assert sw.rays == sa.rays and np.array_equal(whole, again)
+    first, s0 = r.render(w, h, 1, 0)
+    second, s1 = r.render(w, h, 1, 1)
+    assert s0.rays + s1.rays == sw.rays
+    assert np.allclose(first + second, whole, rtol=2e-5, atol=1e-5)
+    del first, second, again
+    assert sw.samples == w * h * 2 and sw.samples <= sw.rays <= 4 * sw.samples
+    assert np.all(np.isfinite(whole)) and np.all(whole >= 0)
+    other, so = r.render(w, h, 2, 2)
+    assert abs(int(so.rays) - int(sw.rays)) < 0.005 * sw.rays
+    la, lb = luminance(whole).mean(), luminance(other).mean()
+    assert abs(la - lb) < 0.1 * la
+    del whole, other
+    # same seed against the oracle (exhaustive search over ten million transformed primitives: a small frame)
+    cw, ch, spp = 32, 18, 1
+    accum, st = r.render(cw, ch, spp)
+    ref, ref_rays = oracle.OracleScene(scene).render(cw, ch, spp, seed=1)
+    assert abs(int(st.rays) - ref_rays) <= 2
+    close = np.isclose(accum, ref, rtol=1e-4, atol=1e-5).all(axis=-1)
+    assert close.mean() >= 0.99 and rel_l1(accum, ref) <= 2e-3
     r.close()
