@@ -181,3 +181,50 @@ def assert_hits_match(got, want, rel_t=1e-5, abs_uv=1e-5):
     assert np.all(np.isclose(got["u"][hit], want["u"][hit], rtol=0, atol=abs_uv, equal_nan=True))
     assert np.all(np.isclose(got["v"][hit], want["v"][hit], rtol=0, atol=abs_uv, equal_nan=True))
     assert np.all(np.isinf(got["t"][~hit]))
+
+
+# ------------------------------------------------------------------------------------------------ device memory
+class DeviceArray:
+    """A float32 array in GPU memory for the tests of the device-pointer entry points: hipMalloc / hipMemcpy / hipFree
+    of the HIP runtime the library itself is linked to (the loader hands back the copy that is already mapped), so that
+    no second GPU runtime is initialised inside the test process."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes as C
+
+            lib = C.CDLL("libamdhip64.so.7")
+            lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            lib.hipFree.argtypes = [C.c_void_p]
+            lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+            lib.hipDeviceSynchronize.argtypes = []
+            lib.hipSetDevice.argtypes = [C.c_int]
+            cls._hip = lib
+        return cls._hip
+
+    def __init__(self, shape, fill_byte=0xFF):
+        import ctypes as C
+
+        self.shape = tuple(shape)
+        self.nbytes = int(np.prod(self.shape)) * 4
+        hip = self.hip()
+        assert hip.hipSetDevice(0) == 0
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), self.nbytes) == 0, "hipMalloc failed"
+        self.ptr = p.value
+        assert hip.hipMemset(self.ptr, fill_byte, self.nbytes) == 0  # 0xFF bytes: NaN in every float
+
+    def numpy(self):
+        hip = self.hip()
+        assert hip.hipDeviceSynchronize() == 0
+        out = np.empty(self.shape, np.float32)
+        assert hip.hipMemcpy(out.ctypes.data, self.ptr, self.nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip().hipFree(self.ptr)
+            self.ptr = None

@@ -10,28 +10,25 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
-def _both(rrt, r, torch, w, h, spp, off):
-    dev = torch.device("cuda", 0)
-    a = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device=dev)
-    b = torch.full((h, w, 3), float("nan"), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    r.render_device(w, h, spp, off, a.data_ptr(), stream)
+def _both(r, w, h, spp, off):
+    a, b = helpers.DeviceArray((h, w, 3)), helpers.DeviceArray((h, w, 3))  # both start as NaN everywhere
+    r.render_device(w, h, spp, off, a.ptr, 0)
     sa = r.render_stats()
-    r.render_device_noalloc(w, h, spp, off, b.data_ptr(), stream)
+    r.render_device_noalloc(w, h, spp, off, b.ptr, 0)
     sb = r.render_stats()
-    torch.cuda.synchronize(dev)
-    return a.cpu().numpy(), sa, b.cpu().numpy(), sb
+    ia, ib = a.numpy(), b.numpy()
+    a.free()
+    b.free()
+    return ia, sa, ib, sb
 
 
 @pytest.mark.parametrize("name", ["mixed", "synthetic", "instanced"])
 def test_noalloc_render_equals_the_allocating_one(rrt, name):
-    import torch
-
     r = rrt.Renderer(device=0, seed=6)
     r.upload(helpers.SCENES[name](rrt))
     # the second call is smaller in every respect: fewer pixels, fewer samples, hence fewer chunks
     for w, h, spp, off in ((200, 112, 50, 3), (71, 40, 9, 0)):
-        a, sa, b, sb = _both(rrt, r, torch, w, h, spp, off)
+        a, sa, b, sb = _both(r, w, h, spp, off)
         assert np.all(np.isfinite(a)) and sa.rays > 0
         assert sa.rays == sb.rays and sa.samples == sb.samples == w * h * spp
         assert np.array_equal(a, b), (name, w, h, spp)
@@ -39,17 +36,16 @@ def test_noalloc_render_equals_the_allocating_one(rrt, name):
 
 
 def test_noalloc_render_refuses_frames_beyond_the_static_workspace(rrt):
-    import torch
-
     r = rrt.Renderer(device=0, seed=6)
     r.upload(helpers.scene_default(rrt))
     w, h, spp = 1920, 1080, 64  # 4 chunks x 24.9 MB of partial images > 64 MiB
-    buf = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda:0")
+    buf = helpers.DeviceArray((h, w, 3))
     with pytest.raises(rrt.RrtError) as e:
-        r.render_device_noalloc(w, h, spp, 0, buf.data_ptr(), 0)
+        r.render_device_noalloc(w, h, spp, 0, buf.ptr, 0)
     assert e.value.status == 1 and "static workspace" in str(e.value)
     # the same frame at one chunk (few samples) needs no partial images and is accepted
-    r.render_device_noalloc(w, h, 2, 0, buf.data_ptr(), 0)
+    r.render_device_noalloc(w, h, 2, 0, buf.ptr, 0)
     st = r.render_stats()
-    assert st.samples == w * h * 2
+    assert st.samples == w * h * 2 and np.all(np.isfinite(buf.numpy()))
+    buf.free()
     r.close()
