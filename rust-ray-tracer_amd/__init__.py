@@ -19,7 +19,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librrt_hip.so")
+# RRT_LIB_PATH: another build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("RRT_LIB_PATH") or os.path.join(_HERE, "librrt_hip.so")
 
 RRT_OK = 0
 STATUS_NAMES = {0: "RRT_OK", 1: "RRT_ERR_INVALID", 2: "RRT_ERR_NO_DEVICE", 3: "RRT_ERR_HIP", 4: "RRT_ERR_OOM",

@@ -8,6 +8,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rrt_layout.h"
 
 namespace rrt {
@@ -172,9 +174,16 @@ struct Best {
 
 __device__ __forceinline__ bool better(float t, uint32_t id, const Best& b) { return t < b.t || id < b.id; }
 
+// Ids of an instance's primitives are id_base + local id (top-level primitives: the local id).  The base is looked up in
+// the instance record when a hit is accepted, which is rare against the number of tests; carried in a register through
+// the walk it would cost the instanced kernels one of the registers their occupancy depends on.
+__device__ __forceinline__ uint32_t instance_id_base(const InstRec* __restrict__ insts, int32_t inst) {
+    return inst >= 0 ? insts[inst].id_base : 0u;
+}
+
 // reference src/geometry/triangle.rs:38-69
 __device__ __forceinline__ void test_triangle(const TriRec* __restrict__ tris, uint32_t idx, V3 o, V3 d, float tmin,
-                                              uint32_t id_base, int32_t inst, Best& best) {
+                                              const InstRec* __restrict__ insts, int32_t inst, Best& best) {
     // 48-byte records at a 32-bit byte offset (two shifts) from the uniform base
     const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + ((idx << 5) + (idx << 4)));
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
@@ -191,7 +200,7 @@ __device__ __forceinline__ void test_triangle(const TriRec* __restrict__ tris, u
             if (v >= 0.0f && v < 1.0f - u) {
                 const float t = dot(e2, qvec) * inv_det;
                 if (t >= tmin && t <= best.t) {
-                    const uint32_t id = id_base + __float_as_uint(q0.w);
+                    const uint32_t id = instance_id_base(insts, inst) + __float_as_uint(q0.w);
                     if (better(t, id, best)) {
                         best.t = t; best.id = id; best.u = u; best.v = v;
                         best.what = (KIND_TRI << 28) | idx; best.inst = inst;
@@ -220,12 +229,12 @@ __device__ __forceinline__ float sphere_root(V3 c, float radius, V3 o, V3 d, flo
 }
 
 __device__ __forceinline__ void test_sphere(const SphereRec* __restrict__ spheres, uint32_t idx, V3 o, V3 d, float tmin,
-                                            uint32_t id_base, int32_t inst, Best& best) {
+                                            const InstRec* __restrict__ insts, int32_t inst, Best& best) {
     const float4 q0 = *reinterpret_cast<const float4*>(&spheres[idx].c[0]);
     const uint32_t lid = spheres[idx].id;
     const float t = sphere_root(v3(q0.x, q0.y, q0.z), q0.w, o, d, tmin, best.t);
     if (t == t) {
-        const uint32_t id = id_base + lid;
+        const uint32_t id = instance_id_base(insts, inst) + lid;
         if (better(t, id, best)) {
             best.t = t; best.id = id; best.u = 0.0f; best.v = 0.0f;
             best.what = (KIND_SPHERE << 28) | idx; best.inst = inst;
@@ -257,12 +266,12 @@ __device__ __forceinline__ bool rect_hit(float a0, float a1, float b0, float b1,
     return false;
 }
 __device__ __forceinline__ void test_rect(const RectRec* __restrict__ rects, uint32_t idx, V3 o, V3 d, float tmin,
-                                          uint32_t id_base, int32_t inst, Best& best) {
+                                          const InstRec* __restrict__ insts, int32_t inst, Best& best) {
     const float4 q0 = *reinterpret_cast<const float4*>(&rects[idx].a0);
     const float4 q1 = *reinterpret_cast<const float4*>(&rects[idx].k);
     float t, u, v;
     if (rect_hit(q0.x, q0.y, q0.z, q0.w, q1.x, __float_as_uint(q1.y) & 3u, o, d, tmin, best.t, t, u, v)) {
-        const uint32_t id = id_base + __float_as_uint(q1.z);
+        const uint32_t id = instance_id_base(insts, inst) + __float_as_uint(q1.z);
         if (better(t, id, best)) {
             best.t = t; best.id = id; best.u = u; best.v = v;
             best.what = (KIND_RECT << 28) | idx; best.inst = inst;
@@ -321,10 +330,23 @@ struct Trav {
     lds_int* top;     // LDS address of this lane's next free stack entry (entries are `stride` ints apart)
     Best best;
     V3 ga, gb;        // slab test constants of the ray on the current BVH's grid: plane q lies at t = q * ga + gb
-    V3 ro, rd;        // ray in the current space (instanced scenes only; otherwise the world ray is used)
-    uint32_t id_base; // id offset of the instance being traversed
     int32_t cur_inst; // instance record being traversed, -1 at top level
 };
+
+// Instanced scenes: a lane's ray registers (o, d) always hold the ray in the space of the BVH it is walking.  Entering
+// an instance parks the world-space ray in LDS (six floats per lane, `stride` floats apart like the stack entries, so a
+// wavefront's access touches consecutive banks) and overwrites the registers with the object-space ray; the exit marker
+// brings the world-space ray back.  Nothing of the world ray is needed while a lane is inside a mesh, and six
+// registers per lane are what separates the instanced kernels from the occupancy of the flat ones.  A walk that is
+// complete has popped every exit marker: its registers hold the world ray again.
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ void wray_park(lds_float* w, int stride, V3 o, V3 d) {
+    w[0] = o.x; w[stride] = o.y; w[2 * stride] = o.z; w[3 * stride] = d.x; w[4 * stride] = d.y; w[5 * stride] = d.z;
+}
+__device__ __forceinline__ void wray_restore(const lds_float* w, int stride, V3& o, V3& d) {
+    o = v3(w[0], w[stride], w[2 * stride]);
+    d = v3(w[3 * stride], w[4 * stride], w[5 * stride]);
+}
 
 // Stack access.  The stack pointer `top` is the LDS address of the lane's next free entry, so that a push or pop
 // needs no address arithmetic beyond moving it by one entry.  K == 0: all STACK_DEPTH entries of a lane live in LDS.
@@ -368,13 +390,15 @@ template <bool INST>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, lds_int* stack, int stride, Trav& T) {
     T.best.t = tmax; T.best.id = 0xFFFFFFFFu; T.best.u = 0.f; T.best.v = 0.f; T.best.what = 0u; T.best.inst = -1;
     trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
-    if (INST) { T.ro = o; T.rd = d; }
-    T.id_base = 0;
     T.cur_inst = -1;
     stack[0] = REF_DONE;
     T.top = stack + stride;
     T.cur = S.root;
 }
+
+// Instanced scenes: the reference is one a lane changes space on (an instance, the marker that ends one) or skips (an
+// empty child): kinds 3..6.  Such a lane is neither descending nor at a leaf; the node pass resolves it.
+__device__ __forceinline__ bool trav_due(int cur) { return (uint32_t)cur - (REF_LEAF | (KIND_INST << 28)) < (4u << 28); }
 
 // Node pass: walks down while the current reference is an inner node (near child first, far child pushed).
 // Lanes that reach a leaf wait outside the loop; once fewer than `min_lanes` lanes are still descending the
@@ -382,10 +406,13 @@ __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float 
 // of lanes run node steps (min_lanes == 0: every lane descends until it is at a leaf).
 // In instanced scenes a lane that comes upon an instance (or upon the marker that ends one) changes its ray's space
 // right here and keeps descending: as a leaf step of its own the change would cost the wavefront a whole pass for
-// the few lanes that need it.  `o`, `d`: the world-space ray (only read when INST).
+// the few lanes that need it.  `o`, `d`: the lane's ray in the space it is walking (only touched when INST: replaced
+// by the object-space ray on entering an instance and by the parked world-space ray on leaving it); `wray`: the lane's
+// slot of the parked world rays (INST only).
 template <bool INST, bool COUNT, int K = 0, int STEPS = 1>
-__device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float tmin, int stride, Trav& T,
-                                           TraceCounters& cnt, uint32_t min_lanes, lds_int* lim = nullptr, int* deep = nullptr) {
+__device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, float tmin, int stride, Trav& T,
+                                           TraceCounters& cnt, uint32_t min_lanes, lds_int* lim = nullptr, int* deep = nullptr,
+                                           lds_float* wray = nullptr) {
     V3 ga = T.ga, gb = T.gb;
     // rotate count of a node's plane pair: 16 where the ray runs against the axis (the sign of ga, the grid step
     // being positive), else 0
@@ -396,8 +423,10 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
     // the pass goes on.
     bool desc = cur >= 0;
     const uint32_t min_go = min_lanes > 1u ? min_lanes : 1u;  // the pass goes on while at least this many lanes descend
-    // one node step of the lanes it is called for
-    auto step = [&]() {
+    // One node step of the lanes it is called for.  `in_window` (a compile-time flag): the caller has established that
+    // every stepping lane's stack top is, and stays for this step, inside the LDS part.
+    auto step = [&](auto in_window) {
+        constexpr bool WINDOW = decltype(in_window)::value;
         // an inner reference is the node's 32-bit byte offset from the uniform base, which the load takes from scalar registers
         const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
         const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
@@ -421,7 +450,7 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
         const bool hl = ln <= lf, hr = rn <= rf;
         const bool any = hl || hr, both = hl && hr;
         int left = (int)a.x, right = (int)a.y;
-        if (K == 0 || __builtin_expect(__ballot(top >= lim) == 0ull, 1)) {
+        if (K == 0 || WINDOW) {
             // Every lane's stack top is inside the LDS part: the step is finished without a branch.  Scalar and
             // branch instructions take issue slots like vector ones, and the four-way case analysis below costs about
             // 25 of them per step.  Here the far child (or, with fewer than two hits, a value nobody will read) is
@@ -447,43 +476,69 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
         } else {
             cur = stack_pop<K>(top, stride, lim, deep);
         }
-        if (INST) {
-            // kinds 3..6: instance, empty child, instance exit marker (the bottom-of-stack marker, kind 7, is not)
-            if ((uint32_t)cur - (REF_LEAF | (KIND_INST << 28)) < (4u << 28)) {
-                const uint32_t kind = ((uint32_t)cur >> 28) & 7u;
-                if (kind == KIND_INST) {
-                    const uint32_t first = (uint32_t)cur & REF_OFFSET_MASK;
-                    const InstRec in = S.insts[first];
-                    to_object_space(in, o, d, T.ro, T.rd);
-                    trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
-                    T.id_base = in.id_base;
-                    T.cur_inst = (int32_t)first;
-                    stack_push<K>(top, stride, lim, deep, REF_INST_EXIT);
-                    cur = in.root;
-                } else {
-                    if (kind == KIND_INST_EXIT) {
-                        T.ro = o; T.rd = d;
-                        trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
-                        T.id_base = 0;
-                        T.cur_inst = -1;
-                    }
-                    cur = stack_pop<K>(top, stride, lim, deep);
+    };
+    // Instanced scenes: a lane whose step ended on an instance reference (or on the marker that ends one, or on an
+    // empty child) changes space here, once per group of steps: written into the step itself, the transition is
+    // repeated in the kernel text for every step of the group and its registers are live across all of them.
+    auto transition = [&]() {
+        if (trav_due(cur)) {
+            const uint32_t kind = ((uint32_t)cur >> 28) & 7u;
+            if (kind == KIND_INST) {
+                const uint32_t first = (uint32_t)cur & REF_OFFSET_MASK;
+                const InstRec in = S.insts[first];
+                wray_park(wray, stride, o, d);
+                to_object_space(in, o, d, o, d);
+                trav_set_ray(T, o, d, in.grid_origin, in.grid_step);
+                T.cur_inst = (int32_t)first;
+                stack_push<K>(top, stride, lim, deep, REF_INST_EXIT);
+                cur = in.root;
+            } else {
+                if (kind == KIND_INST_EXIT) {
+                    wray_restore(wray, stride, o, d);
+                    trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
+                    T.cur_inst = -1;
                 }
-                ga = T.ga; gb = T.gb;
-                rx = (__float_as_uint(ga.x) >> 31) << 4; ry = (__float_as_uint(ga.y) >> 31) << 4; rz = (__float_as_uint(ga.z) >> 31) << 4;
+                cur = stack_pop<K>(top, stride, lim, deep);
             }
+            ga = T.ga; gb = T.gb;
+            rx = (__float_as_uint(ga.x) >> 31) << 4; ry = (__float_as_uint(ga.y) >> 31) << 4; rz = (__float_as_uint(ga.z) >> 31) << 4;
         }
     };
+    // STEPS steps between two votes on whether the pass goes on (loop control is a tenth of a step: measured on the
+    // 1M-triangle scene, 1 / 2 / 3 / 4 steps per vote run in 175.6 / 172.1 / 170.3 / 170.9 ms).  Whether the steps of a
+    // group may use the branch-free ending is decided once per group, not once per step: a step raises a lane's top
+    // by at most one entry, so if every descending lane's top lies at least STEPS - 1 entries below the end of the LDS
+    // part when the group starts, it is inside the part for all of the group's steps.
+    unsigned long long desc_m = __builtin_amdgcn_ballot_w64(desc);
     for (;;) {
-      if (desc) step();
-      // further steps before the pass is put to the vote again (loop control is a tenth of a step): measured on the
-      // 1M-triangle scene, 1 / 2 / 3 / 4 steps per vote run in 175.6 / 172.1 / 170.3 / 170.9 ms
-#pragma unroll
-      for (int extra = 1; extra < STEPS; ++extra) {
-          if (cur >= 0) step();
+      if (INST) {
+          // lanes due for a transition take it first and descend (or wait at a leaf) in their new space
+          transition();
+          desc = cur >= 0;
+          desc_m = __builtin_amdgcn_ballot_w64(desc);
       }
+      const bool window = K == 0 || (__builtin_amdgcn_ballot_w64(top + (STEPS - 1) * stride >= lim) & desc_m) == 0ull;
+      if (__builtin_expect(window, 1)) {
+          if (desc) step(std::true_type{});
+#pragma unroll
+          for (int extra = 1; extra < STEPS; ++extra) {
+              if (cur >= 0) step(std::true_type{});
+          }
+      } else {
+          if (desc) step(std::false_type{});
+#pragma unroll
+          for (int extra = 1; extra < STEPS; ++extra) {
+              if (cur >= 0) step(std::false_type{});
+          }
+      }
+      // the pass goes on for the lanes that descend and for those due for a transition (which descend after it)
       desc = cur >= 0;
-      if ((uint32_t)__popcll(__ballot(desc)) < min_go) break;
+      if (INST) {
+          if ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(desc || trav_due(cur))) < min_go) break;
+      } else {
+          desc_m = __builtin_amdgcn_ballot_w64(desc);
+          if ((uint32_t)__popcll(desc_m) < min_go) break;
+      }
     }
     T.cur = cur;
     T.top = top;
@@ -495,17 +550,19 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3 o, V3 d, float 
 // Precondition: T.cur is negative and not REF_DONE.
 // PAIR: a triangle leaf with at least two records left has two of them tested in one step.
 template <bool INST, bool COUNT, int K = 0, bool PAIR = false>
-__device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float tmin, int stride, Trav& T,
-                                          TraceCounters& cnt, lds_int* lim = nullptr, int* deep = nullptr) {
+__device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float tmin, int stride, Trav& T,
+                                          TraceCounters& cnt, lds_int* lim = nullptr, int* deep = nullptr,
+                                          lds_float* wray = nullptr) {
     const uint32_t ref = (uint32_t)T.cur;
     const uint32_t kind = (ref >> 28) & 7u;
     const uint32_t first = ref & REF_OFFSET_MASK;
-    const V3 ro = INST ? T.ro : o, rd = INST ? T.rd : d;
+    const V3 ro = o, rd = d;  // the ray in the space being walked
+    const InstRec* insts = INST ? S.insts : nullptr;
     // The common case, decided once for the wavefront: every lane of the pass is at a triangle and the entry below
     // its stack top is in LDS.  The step then ends without a branch: the entry below the top is read in any case and
     // becomes current, and the top moves down, only if the leaf has no triangle left.
     if (__builtin_expect(__ballot(kind != KIND_TRI || (K > 0 && T.top - stride >= lim)) == 0ull, 1)) {
-        test_triangle(S.tris, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+        test_triangle(S.tris, first, ro, rd, tmin, insts, T.cur_inst, T.best);
         if (COUNT) {
             cnt.prims++;
             if (first_active_lane()) cnt.wave_prims++;
@@ -518,7 +575,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         bool more = ((r >> 25) & 7u) != 0u;
         if (PAIR && more) {
             r += 1u - (1u << 25);  // next record, one triangle fewer
-            test_triangle(S.tris, r & REF_OFFSET_MASK, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+            test_triangle(S.tris, r & REF_OFFSET_MASK, ro, rd, tmin, insts, T.cur_inst, T.best);
             if (COUNT) {
                 cnt.prims++;
                 if (first_active_lane()) cnt.wave_prims++;
@@ -532,7 +589,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
         return;
     }
     if (kind == KIND_TRI) {
-        test_triangle(S.tris, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+        test_triangle(S.tris, first, ro, rd, tmin, insts, T.cur_inst, T.best);
         if (COUNT) {
             cnt.prims++;
             if (first_active_lane()) cnt.wave_prims++;
@@ -542,24 +599,23 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
             return;
         }
     } else if (kind == KIND_SPHERE) {
-        test_sphere(S.spheres, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+        test_sphere(S.spheres, first, ro, rd, tmin, insts, T.cur_inst, T.best);
         if (COUNT) cnt.prims++;
     } else if (kind == KIND_RECT) {
-        test_rect(S.rects, first, ro, rd, tmin, T.id_base, T.cur_inst, T.best);
+        test_rect(S.rects, first, ro, rd, tmin, insts, T.cur_inst, T.best);
         if (COUNT) cnt.prims++;
     } else if (INST && kind == KIND_INST) {
         const InstRec in = S.insts[first];
-        to_object_space(in, o, d, T.ro, T.rd);
-        trav_set_ray(T, T.ro, T.rd, in.grid_origin, in.grid_step);
-        T.id_base = in.id_base;
+        wray_park(wray, stride, o, d);
+        to_object_space(in, o, d, o, d);
+        trav_set_ray(T, o, d, in.grid_origin, in.grid_step);
         T.cur_inst = (int32_t)first;
         stack_push<K>(T.top, stride, lim, deep, REF_INST_EXIT);
         T.cur = in.root;
         return;
     } else if (INST && kind == KIND_INST_EXIT) {
-        T.ro = o; T.rd = d;
+        wray_restore(wray, stride, o, d);
         trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
-        T.id_base = 0;
         T.cur_inst = -1;
     }
     T.cur = stack_pop<K>(T.top, stride, lim, deep);
@@ -568,12 +624,12 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3 o, V3 d, float t
 // Complete walk of one ray (used by the ray-batch kernel): the same passes as the render kernel, run to the end.
 template <bool INST, bool COUNT>
 __device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin, float tmax, lds_int* stack, int stride,
-                                      Best& best, TraceCounters& cnt) {
+                                      Best& best, TraceCounters& cnt, lds_float* wray = nullptr) {
     Trav T;
     trav_begin<INST>(S, o, d, tmax, stack, stride, T);
     while (T.cur != REF_DONE) {
-        trav_nodes<INST, COUNT>(S, o, d, tmin, stride, T, cnt, 0u);  // 0: descend until this lane is at a leaf
-        if (T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stride, T, cnt);
+        trav_nodes<INST, COUNT>(S, o, d, tmin, stride, T, cnt, 0u, nullptr, nullptr, wray);  // 0: descend until this lane is at a leaf
+        if (T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stride, T, cnt, nullptr, nullptr, wray);
     }
     best = T.best;
 }

@@ -28,6 +28,12 @@ static constexpr int RENDER_STACK = 16;   // traversal stack entries per lane th
 // (With 20 the private remainder is 19 entries, small enough for the compiler to turn it into registers: the one-item
 // form then spills 95 of them and runs eight times slower.  Larger LDS parts bought nothing anyway: walks seldom
 // leave the first 16 entries.)
+#ifndef RRT_INST_WAVES
+#define RRT_INST_WAVES 7  // workgroups per CU (= wavefronts per SIMD) the instanced forms of k_render are compiled for
+#endif
+#ifndef RRT_INST_STACK
+#define RRT_INST_STACK 16  // ... and the traversal stack entries per lane they keep in LDS
+#endif
 static constexpr uint32_t N_QUEUES = 8;   // workgroup ids congruent mod 8 are dealt to one XCD and share its L2
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -51,19 +57,21 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 }
 
 template <bool INST, bool COUNT, bool PIPELINED>
-__global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+__global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 7 : 6)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
-    // Flat scenes keep RENDER_STACK entries per lane in LDS (six workgroups per CU, seven in the pipelined form, whose
-    // large scenes gain more from the extra wavefront than they lose to its spills); instanced scenes, whose kernel
-    // needs more registers than six or five waves per SIMD leave it, keep the whole stack there (four per CU).
-    constexpr int K = INST ? 0 : RENDER_STACK;
-    __shared__ int s_stack[(INST ? STACK_DEPTH : RENDER_STACK) * RENDER_BLOCK];
+    // RENDER_STACK entries per lane of the traversal stack live in LDS, the rest in private memory (six workgroups per
+    // CU, seven in the pipelined form, whose large scenes gain more from the extra wavefront than they lose to its
+    // spills).  Instanced scenes add six floats per lane for the world-space ray of a lane that walks inside a mesh.
+    constexpr int K = INST ? RRT_INST_STACK : RENDER_STACK;
+    __shared__ int s_stack[K * RENDER_BLOCK];
+    __shared__ float s_wray[INST ? 6 * RENDER_BLOCK : 1];
     __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 16];  // per wavefront: the records of its two work items
     const uint32_t lane = threadIdx.x & 63u;
     lds_int* stack = (lds_int*)(s_stack + threadIdx.x);
+    lds_float* wray = INST ? (lds_float*)(s_wray + threadIdx.x) : nullptr;
     lds_int* lim = (lds_int*)s_stack + K * RENDER_BLOCK;  // where entry K of the first lane would lie: the end of the LDS part
-    int deep[STACK_DEPTH - RENDER_STACK];  // stack entries below the LDS window (private memory; rarely touched)
+    int deep[STACK_DEPTH - K];  // stack entries below the LDS window (private memory; rarely touched)
     const uint32_t width = G.width, height = G.height;
     const V3 bg = v3(S.background[0], S.background[1], S.background[2]);
 
@@ -145,14 +153,15 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                     if (n_walk == 0u) break;
                     // the last few walkers of a trip are left to finish in the next one, once enough lanes wait to shade
                     if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
-                    const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
+                    // (instanced scenes: a lane due for a change of space counts as descending, the node pass resolves it)
+                    const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0 || (INST && trav_due(T.cur))));
                     const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
                     if (n_desc >= share) {  // share <= n_walk, so a pass in which every walker descends always runs
                         if (COUNT) {
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
                             const uint32_t nodes0 = cnt.nodes;
-                            trav_nodes<INST, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
+                            trav_nodes<INST, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                             uint32_t steps = cnt.nodes - nodes0;
                             for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                             if (lane == 0u) {
@@ -160,10 +169,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                                 slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                             }
                         } else {
-                            trav_nodes<INST, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
+                            trav_nodes<INST, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         }
                     }
-                    if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep);
+                    if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray);
                 }
                 // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
                 if (has_ray && T.cur == REF_DONE) {
@@ -282,14 +291,15 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                 if (n_walk == 0u) break;
                 // the last few walkers of a trip are left to finish in the next one, once enough lanes wait to shade
                 if (n_walk <= G.leave_walk && (uint32_t)__popcll(__ballot(has_ray && T.cur == REF_DONE)) >= G.leave_ready) break;
-                const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
+                // (instanced scenes: a lane due for a change of space counts as descending, the node pass resolves it)
+                const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0 || (INST && trav_due(T.cur))));
                 const uint32_t share = (n_walk * G.node_share_64ths) >> 6;
                 if (n_desc >= share) {  // share <= n_walk, so a pass in which every walker descends always runs
                     if (COUNT) {
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<INST, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
+                        trav_nodes<INST, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                         if (lane == 0u) {
@@ -297,10 +307,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 4 : (PIPELINED ? 7 : 6)) void 
                             slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                         }
                     } else {
-                        trav_nodes<INST, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep);
+                        trav_nodes<INST, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                     }
                 }
-                if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep);
+                if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<INST, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray);
             }
 
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
@@ -424,6 +434,7 @@ template <bool INST>
 __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* __restrict__ rays, size_t n, float tmin,
                                                     float tmax, rrt_hit* __restrict__ out) {
     __shared__ int s_stack[STACK_DEPTH * WAVE];
+    __shared__ float s_wray[INST ? 6 * WAVE : 1];
     const size_t i = (size_t)blockIdx.x * WAVE + threadIdx.x;
     if (i >= n) return;
     const rrt_ray r = rays[i];
@@ -431,7 +442,8 @@ __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* _
     const V3 d = v3(r.direction[0], r.direction[1], r.direction[2]);
     Best best;
     TraceCounters cnt = {0u, 0u, 0u, 0u, 0u};
-    trace<INST, false>(S, o, d, tmin, tmax, (lds_int*)(s_stack + threadIdx.x), WAVE, best, cnt);
+    trace<INST, false>(S, o, d, tmin, tmax, (lds_int*)(s_stack + threadIdx.x), WAVE, best, cnt,
+                       INST ? (lds_float*)(s_wray + threadIdx.x) : nullptr);
     out[i] = hit_record(S, best, o, d);
 }
 
@@ -442,14 +454,17 @@ __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* _
 // about 10 ns per add, which would otherwise bound the kernel); whenever at least `refill_min` lanes of a
 // wavefront are idle, they take the next indices of the wavefront's block.  counters (COUNT only): {-, node visits, primitive tests, node passes, primitive
 // passes, -, refill passes}.
+// (Instanced scenes: the parked world rays bring the workgroup's LDS to 45 KB, three workgroups per CU.)
 template <bool INST, bool COUNT>
-__global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, const rrt_ray* __restrict__ rays, uint32_t n,
+__global__ __launch_bounds__(RENDER_BLOCK, INST ? 3 : 4) void k_trace_stream(SceneDev S, const rrt_ray* __restrict__ rays, uint32_t n,
                                                                   float tmin, float tmax, rrt_hit* __restrict__ out,
                                                                   unsigned int* __restrict__ head, uint32_t refill_min,
                                                                   uint32_t node_share_64ths,
                                                                   unsigned long long* __restrict__ counters) {
     __shared__ int s_stack[STACK_DEPTH * RENDER_BLOCK];
+    __shared__ float s_wray[INST ? 6 * RENDER_BLOCK : 1];
     lds_int* stack = (lds_int*)(s_stack + threadIdx.x);
+    lds_float* wray = INST ? (lds_float*)(s_wray + threadIdx.x) : nullptr;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t mine = 0xFFFFFFFFu;  // index of the ray this lane is walking (or has walked and not yet written)
     V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
@@ -494,10 +509,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, 4) void k_trace_stream(SceneDev S, co
             continue;
         }
         const uint32_t n_walk = 64u - n_idle;
-        const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0));
+        const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0 || (INST && trav_due(T.cur))));
         const uint32_t share = (n_walk * node_share_64ths) >> 6;
-        if (n_desc >= share) trav_nodes<INST, COUNT, 0, 3>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share);
-        if (T.cur < 0 && T.cur != REF_DONE) trav_leaf<INST, COUNT, 0, true>(S, o, d, tmin, RENDER_BLOCK, T, cnt);
+        if (n_desc >= share) trav_nodes<INST, COUNT, 0, 3>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share, nullptr, nullptr, wray);
+        if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<INST, COUNT, 0, true>(S, o, d, tmin, RENDER_BLOCK, T, cnt, nullptr, nullptr, wray);
     }
     if (COUNT) {
         const unsigned long long nn = wave_sum((unsigned long long)cnt.nodes);
