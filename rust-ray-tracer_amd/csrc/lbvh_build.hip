@@ -1,5 +1,13 @@
 // lbvh_build.hip -- linear BVH on the GPU: 48-bit Morton codes -> radix sort -> radix-tree topology (every inner node
-// from the sorted codes alone, Karras 2012) -> boxes bottom-up, one kernel launch per tree level.
+// from the sorted codes alone, Karras 2012) -> boxes bottom-up, one kernel launch per tree level -> (optionally) the
+// levels above a cut rebuilt with the surface-area heuristic over the subtrees below it.
+//
+// A radix tree splits where Morton codes change, which is a poor place near the root (children that overlap or span
+// empty space) and a fair one near the leaves (a few neighbouring primitives).  The hybrid keeps the radix tree's
+// small subtrees ("clusters", at most cluster_size primitives: contiguous runs of the sorted order, so their triangle
+// leaves stay contiguous runs of records) and replaces everything above them: the clusters' boxes go to the host's
+// binned SAH builder (n / cluster_size-ish items instead of n), and its nodes are written into the slots of the radix
+// nodes they replace -- a binary tree over c clusters has c - 1 inner nodes either way.
 //
 // The bottom-up pass hands boxes from children to parents only ACROSS kernel launches: a node is finished in
 // launch k if both children were finished in launches < k.  Inside one launch nothing written by another
@@ -10,10 +18,18 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <vector>
+
 namespace rrt {
 namespace {
 
-constexpr uint32_t LBVH_LEAF_TRIS = 4;  // a subtree of at most this many primitives, all triangles, becomes one leaf
+// A radix subtree of at most this many primitives, all triangles, becomes one leaf (experiment knob RRT_LBVH_LEAF).
+// Measured on MI355X with the upper levels rebuilt: 2 -- the two triangles of a quad, what the host's SAH leaves
+// mostly are -- renders faster than 4, whose leaves cost nearly twice the primitive tests per ray.
+constexpr uint32_t LBVH_LEAF_TRIS_DEFAULT = 2;
 constexpr int BLOCK = 256;
 
 struct LeafInfo {  // one sorted primitive
@@ -90,7 +106,7 @@ __device__ __forceinline__ int common_prefix(const unsigned long long* __restric
     return 64 + __clz((int)((unsigned)i ^ (unsigned)j));
 }
 
-__global__ void k_topology(const unsigned long long* __restrict__ keys, int n, Topo* __restrict__ topo) {
+__global__ void k_topology(const unsigned long long* __restrict__ keys, int n, Topo* __restrict__ topo, int* __restrict__ parent) {
     const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
     if (i >= n - 1) return;
     const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
@@ -114,6 +130,9 @@ __global__ void k_topology(const unsigned long long* __restrict__ keys, int n, T
     o.left = o.first == gamma ? ~gamma : gamma;
     o.right = o.last == gamma + 1 ? ~(gamma + 1) : gamma + 1;
     topo[i] = o;
+    if (o.left >= 0) parent[o.left] = i;
+    if (o.right >= 0) parent[o.right] = i;
+    if (i == 0) parent[0] = -1;
 }
 
 struct ChildView {
@@ -125,7 +144,7 @@ struct ChildView {
 
 __device__ __forceinline__ ChildView view_child(int c, const Topo* __restrict__ topo, const LeafInfo* __restrict__ leaf,
                                                 const uint32_t* __restrict__ tri_prefix, const NodeState* __restrict__ st,
-                                                uint32_t launch, uint32_t node_base, uint32_t tri_base) {
+                                                uint32_t launch, uint32_t node_base, uint32_t tri_base, uint32_t leaf_tris) {
     ChildView v;
     if (c < 0) {
         const int pos = ~c;
@@ -142,7 +161,7 @@ __device__ __forceinline__ ChildView view_child(int c, const Topo* __restrict__ 
     for (int a = 0; a < 3; ++a) { v.mn[a] = s.mn[a]; v.mx[a] = s.mx[a]; }
     const Topo t = topo[c];
     const uint32_t cnt = (uint32_t)(t.last - t.first + 1);
-    if (cnt <= LBVH_LEAF_TRIS && tri_prefix[t.last + 1] - tri_prefix[t.first] == cnt) {
+    if (cnt <= leaf_tris && tri_prefix[t.last + 1] - tri_prefix[t.first] == cnt) {
         v.ref = (int32_t)make_leaf_ref(KIND_TRI, tri_base + tri_prefix[t.first], cnt);
         v.depth = 0u;
     } else {
@@ -154,14 +173,14 @@ __device__ __forceinline__ ChildView view_child(int c, const Topo* __restrict__ 
 
 __global__ void k_refit(const Topo* __restrict__ topo, const LeafInfo* __restrict__ leaf, const uint32_t* __restrict__ tri_prefix,
                         NodeState* __restrict__ st, QNode* __restrict__ nodes, uint32_t n, uint32_t launch, Grid g,
-                        uint32_t node_base, uint32_t tri_base) {
+                        uint32_t node_base, uint32_t tri_base, uint32_t leaf_tris) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n - 1u) return;
     if (st[i].done != 0u) return;
     const Topo t = topo[i];
-    const ChildView l = view_child(t.left, topo, leaf, tri_prefix, st, launch, node_base, tri_base);
+    const ChildView l = view_child(t.left, topo, leaf, tri_prefix, st, launch, node_base, tri_base, leaf_tris);
     if (!l.ready) return;
-    const ChildView r = view_child(t.right, topo, leaf, tri_prefix, st, launch, node_base, tri_base);
+    const ChildView r = view_child(t.right, topo, leaf, tri_prefix, st, launch, node_base, tri_base, leaf_tris);
     if (!r.ready) return;
     QNode q;
     q.left = device_ref(l.ref);
@@ -174,6 +193,58 @@ __global__ void k_refit(const Topo* __restrict__ topo, const LeafInfo* __restric
     s.depth = 1u + (l.depth > r.depth ? l.depth : r.depth);
     s.done = launch;
     st[i] = s;
+}
+
+// One subtree below the cut, as the host's builder sees it.
+struct Cluster {
+    float mn[3];
+    int32_t ref;     // what a parent stores for it: a leaf reference or the subtree's node index (not yet a device reference)
+    float mx[3];
+    uint32_t depth;  // node levels of the subtree
+    uint32_t first;  // first sorted position it covers (gives the clusters a fixed order)
+    uint32_t pad;
+};
+
+// The cut: radix nodes over more than `cluster_size` primitives are "upper" nodes (to be replaced), and every child of
+// an upper node that is not itself upper is a cluster.  counters[0]: upper nodes, counters[1]: clusters,
+// counters[2]: set if a cluster was not finished by the refit launches.
+__global__ void k_cut(const Topo* __restrict__ topo, const LeafInfo* __restrict__ leaf, const uint32_t* __restrict__ tri_prefix,
+                      const NodeState* __restrict__ st, uint32_t n, uint32_t cluster_size, uint32_t node_base, uint32_t tri_base,
+                      uint32_t leaf_tris, uint32_t* __restrict__ upper, Cluster* __restrict__ clusters, uint32_t capacity,
+                      uint32_t* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n - 1u) return;
+    const Topo t = topo[i];
+    if ((uint32_t)(t.last - t.first + 1) <= cluster_size) return;
+    const uint32_t u = atomicAdd(&counters[0], 1u);
+    if (u < capacity) upper[u] = i;
+    const int child[2] = {t.left, t.right};
+    for (int k = 0; k < 2; ++k) {
+        const int c = child[k];
+        uint32_t first;
+        if (c >= 0) {
+            const Topo tc = topo[c];
+            if ((uint32_t)(tc.last - tc.first + 1) > cluster_size) continue;  // upper as well
+            first = (uint32_t)tc.first;
+        } else {
+            first = (uint32_t)~c;
+        }
+        const ChildView v = view_child(c, topo, leaf, tri_prefix, st, 0xFFFFFFFFu, node_base, tri_base, leaf_tris);
+        if (!v.ready) counters[2] = 1u;
+        Cluster o;
+        for (int a = 0; a < 3; ++a) { o.mn[a] = v.mn[a]; o.mx[a] = v.mx[a]; }
+        o.ref = v.ref;
+        o.depth = v.depth;
+        o.first = first;
+        o.pad = 0u;
+        const uint32_t at = atomicAdd(&counters[1], 1u);
+        if (at < capacity) clusters[at] = o;  // the host sees the overflow in the counter and keeps the radix tree
+    }
+}
+
+__global__ void k_scatter_nodes(const QNode* __restrict__ src, const uint32_t* __restrict__ slot, uint32_t m, QNode* __restrict__ nodes) {
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    if (k < m) nodes[slot[k]] = src[k];
 }
 
 // Triangle records into leaf order: sorted position j holds the triangle with ordinal leaf[j].index.
@@ -191,12 +262,11 @@ __global__ void k_permute_tris(const LeafInfo* __restrict__ leaf, const uint32_t
 }
 
 struct Buffers {
-    void* p[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int used = 0;
+    std::vector<void*> p;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~Buffers() {
-        for (int i = 0; i < used; ++i)
-            if (p[i]) (void)hipFree(p[i]);
+        for (void* q : p)
+            if (q) (void)hipFree(q);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     }
@@ -205,7 +275,7 @@ struct Buffers {
         void* q = nullptr;
         hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
         if (e != hipSuccess) return e;
-        p[used++] = q;
+        p.push_back(q);
         *out = static_cast<T*>(q);
         return hipSuccess;
     }
@@ -219,10 +289,78 @@ struct Buffers {
 
 }  // namespace
 
+// The levels above the cut, rebuilt: clusters and upper nodes are fetched, the host's SAH builder runs over the
+// clusters' boxes, and its nodes go into the upper nodes' slots (the root keeps slot 0).  Returns the depth of the
+// finished tree in *depth (0: not done -- too many clusters for the buffers, an unfinished cluster, a tree deeper than
+// max_depth; the plain radix tree is then what d_nodes holds).
+static hipError_t rebuild_top(const uint32_t* d_upper, const Cluster* d_clusters, const uint32_t* d_counters, uint32_t capacity,
+                              const Grid& grid, QNode* d_nodes, uint32_t node_base, uint32_t max_depth, unsigned threads,
+                              Buffers& B, uint32_t* depth, uint32_t* n_clusters) {
+    *depth = 0;
+    *n_clusters = 0;
+    uint32_t counters[3] = {0u, 0u, 0u};
+    LBVH_TRY(hipMemcpy(counters, d_counters, sizeof counters, hipMemcpyDeviceToHost));
+    const uint32_t n_upper = counters[0], n_cl = counters[1];
+    if (counters[2] != 0u || n_cl < 2u || n_cl > capacity || n_upper > capacity || n_upper + 1u != n_cl) return hipSuccess;
+    std::vector<uint32_t> upper(n_upper);
+    std::vector<Cluster> cl(n_cl);
+    LBVH_TRY(hipMemcpy(upper.data(), d_upper, (size_t)n_upper * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    LBVH_TRY(hipMemcpy(cl.data(), d_clusters, (size_t)n_cl * sizeof(Cluster), hipMemcpyDeviceToHost));
+    // the kernel appended in whatever order its threads ran: a fixed order makes the build reproducible
+    std::sort(upper.begin(), upper.end());
+    std::sort(cl.begin(), cl.end(), [](const Cluster& a, const Cluster& b) { return a.first < b.first; });
+    if (upper[0] != 0u) return hipSuccess;  // the radix root is always an upper node
+    uint32_t deepest = 0;
+    std::vector<BuildPrim> prims(n_cl);
+    for (uint32_t k = 0; k < n_cl; ++k) {
+        for (int a = 0; a < 3; ++a) { prims[k].bmin[a] = cl[k].mn[a]; prims[k].bmax[a] = cl[k].mx[a]; }
+        prims[k].kind = KIND_SUBTREE;
+        prims[k].index = k;
+        deepest = std::max(deepest, cl[k].depth);
+    }
+    if (deepest + 1u >= max_depth) return hipSuccess;
+    std::vector<BvhNode> top;
+    std::vector<uint32_t> no_tris;
+    const BuildResult br = build_bvh(prims, top, no_tris, 0u, max_depth - deepest, threads);
+    if (br.depth + deepest > max_depth || top.size() != (size_t)n_upper) return hipSuccess;
+    // builder node k -> slot upper[k] (node 0, the root, -> slot 0); cluster ordinals -> the clusters' references
+    auto final_ref = [&](int32_t ref) -> int32_t {
+        if (ref >= 0) return device_ref((int32_t)(node_base + upper[(uint32_t)ref]));
+        const uint32_t u = (uint32_t)ref, kind = (u >> 28) & 7u;
+        if (kind != KIND_SUBTREE) return ref;  // an empty child slot
+        return device_ref(cl[u & REF_OFFSET_MASK].ref);
+    };
+    std::vector<QNode> q(top.size());
+    std::vector<uint32_t> slot(top.size());
+    for (size_t k = 0; k < top.size(); ++k) {
+        q[k].left = final_ref(top[k].left);
+        q[k].right = final_ref(top[k].right);
+        quantize_box(grid, top[k].lmin, top[k].lmax, q[k].lbox);
+        quantize_box(grid, top[k].rmin, top[k].rmax, q[k].rbox);
+        slot[k] = node_base + upper[k];
+    }
+    QNode* d_q;
+    uint32_t* d_slot;
+    LBVH_TRY(B.alloc(&d_q, q.size()));
+    LBVH_TRY(B.alloc(&d_slot, slot.size()));
+    LBVH_TRY(hipMemcpy(d_q, q.data(), q.size() * sizeof(QNode), hipMemcpyHostToDevice));
+    LBVH_TRY(hipMemcpy(d_slot, slot.data(), slot.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    const uint32_t m = (uint32_t)q.size();
+    hipLaunchKernelGGL(k_scatter_nodes, dim3((m + BLOCK - 1u) / BLOCK), dim3(BLOCK), 0, (hipStream_t)0, d_q, d_slot, m, d_nodes);
+    LBVH_TRY(hipGetLastError());
+    LBVH_TRY(hipDeviceSynchronize());
+    *depth = br.depth + deepest;
+    *n_clusters = n_cl;
+    return hipSuccess;
+}
+
 hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QNode* d_nodes, uint32_t node_base,
-                      TriRec* d_tris, uint32_t tri_base, uint32_t tri_count, uint32_t max_depth, LbvhResult* out) {
+                      TriRec* d_tris, uint32_t tri_base, uint32_t tri_count, uint32_t max_depth, uint32_t cluster_size,
+                      unsigned threads, LbvhResult* out) {
     out->depth = 0;
     out->build_ms = 0.f;
+    out->clusters = 0;
+    out->top_ms = 0.f;
     if (n < 2u || n > REF_OFFSET_MASK) return hipErrorInvalidValue;
     Buffers B;
     BuildPrim* d_prims;
@@ -243,6 +381,19 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QN
     LBVH_TRY(B.alloc(&topo, n));
     LBVH_TRY(B.alloc(&st, n));
     LBVH_TRY(B.alloc(&tri_tmp, tri_count));
+    int* parent;
+    LBVH_TRY(B.alloc(&parent, n));
+    // buffers of the cut: about 2 n / cluster_size clusters are to be expected; a tree that yields more than
+    // 8 n / cluster_size + 1024 keeps its radix topology
+    const bool cut = cluster_size >= 2u && n > 2u * cluster_size;
+    const uint32_t capacity = cut ? (uint32_t)std::min<uint64_t>(n, 8ull * n / cluster_size + 1024ull) : 0u;
+    uint32_t *d_upper = nullptr, *d_counters = nullptr;
+    Cluster* d_clusters = nullptr;
+    if (cut) {
+        LBVH_TRY(B.alloc(&d_upper, capacity));
+        LBVH_TRY(B.alloc(&d_clusters, capacity));
+        LBVH_TRY(B.alloc(&d_counters, 4));
+    }
     size_t sort_bytes = 0, scan_bytes = 0;
     LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 48, (hipStream_t)0));
     LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_tri, tri_prefix, (int)(n + 1u), (hipStream_t)0));
@@ -259,13 +410,15 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QN
     LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(temp, sort_bytes, keys_a, keys_b, vals_a, vals_b, (int)n, 0, 48, s));
     hipLaunchKernelGGL(k_gather, dim3(blocks1), dim3(BLOCK), 0, s, d_prims, vals_b, n, leaf, is_tri);
     LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(temp, scan_bytes, is_tri, tri_prefix, (int)(n + 1u), s));
-    hipLaunchKernelGGL(k_topology, dim3(blocks), dim3(BLOCK), 0, s, keys_b, (int)n, topo);
+    hipLaunchKernelGGL(k_topology, dim3(blocks), dim3(BLOCK), 0, s, keys_b, (int)n, topo, parent);
     LBVH_TRY(hipMemsetAsync(st, 0, (size_t)n * sizeof(NodeState), s));
-    // a tree whose collapsed depth fits max_depth has at most max_depth + 3 radix-tree levels (a collapsed subtree
-    // of at most 4 leaves is at most 3 levels high)
-    const uint32_t launches = max_depth + 3u;
+    // a tree whose collapsed depth fits max_depth has at most max_depth + 7 radix-tree levels (a collapsed subtree
+    // of at most MAX_LEAF_TRIS = 8 leaves is at most 7 levels high)
+    const uint32_t launches = max_depth + 7u;
+    uint32_t leaf_tris = LBVH_LEAF_TRIS_DEFAULT;
+    if (const char* e = getenv("RRT_LBVH_LEAF")) leaf_tris = (uint32_t)std::min(std::max(atoi(e), 1), (int)MAX_LEAF_TRIS);
     for (uint32_t k = 1; k <= launches; ++k)
-        hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BLOCK), 0, s, topo, leaf, tri_prefix, st, d_nodes, n, k, grid, node_base, tri_base);
+        hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BLOCK), 0, s, topo, leaf, tri_prefix, st, d_nodes, n, k, grid, node_base, tri_base, leaf_tris);
     if (tri_count) {
         LBVH_TRY(hipMemcpyAsync(tri_tmp, d_tris + tri_base, (size_t)tri_count * sizeof(TriRec), hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_permute_tris, dim3(blocks), dim3(BLOCK), 0, s, leaf, tri_prefix, n, tri_tmp, tri_count, d_tris + tri_base);
@@ -276,6 +429,21 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QN
     LBVH_TRY(hipMemcpy(&root, st, sizeof root, hipMemcpyDeviceToHost));  // also waits for the stream
     LBVH_TRY(hipEventElapsedTime(&out->build_ms, B.e0, B.e1));
     if (root.done != 0u && root.depth <= max_depth) out->depth = root.depth;
+    if (cut) {
+        // the radix tree above the cut need not fit the depth bound (nor be finished): only the clusters must
+        const auto t0 = std::chrono::steady_clock::now();
+        LBVH_TRY(hipMemsetAsync(d_counters, 0, 4 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_cut, dim3(blocks), dim3(BLOCK), 0, s, topo, leaf, tri_prefix, st, n, cluster_size, node_base, tri_base,
+                           leaf_tris, d_upper, d_clusters, capacity, d_counters);
+        LBVH_TRY(hipGetLastError());
+        uint32_t depth = 0, n_clusters = 0;
+        LBVH_TRY(rebuild_top(d_upper, d_clusters, d_counters, capacity, grid, d_nodes, node_base, max_depth, threads, B, &depth, &n_clusters));
+        if (depth != 0u) {
+            out->depth = depth;
+            out->clusters = n_clusters;
+        }
+        out->top_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     return hipSuccess;
 }
 

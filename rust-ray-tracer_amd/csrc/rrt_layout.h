@@ -28,6 +28,7 @@ namespace rrt {
 //   bit31 set            : leaf;  bits 30..28 = kind, bits 27..25 = count-1 (triangles), bits 24..0 = first record
 static constexpr uint32_t REF_LEAF = 0x80000000u;
 static constexpr uint32_t KIND_TRI = 0u, KIND_SPHERE = 1u, KIND_RECT = 2u, KIND_INST = 3u;
+static constexpr uint32_t KIND_SUBTREE = 4u;    // builder-internal: a primitive that stands for a finished subtree (never stored in a node)
 static constexpr uint32_t KIND_EMPTY = 5u;      // child slot without content (scenes with fewer than two primitives)
 static constexpr uint32_t KIND_INST_EXIT = 6u;  // traversal stack marker: leave the instance's object space
 static constexpr uint32_t KIND_DONE = 7u;       // traversal stack marker: bottom of stack / empty child

@@ -60,13 +60,11 @@ def test_full_size_mesh(rrt, oracle):
     host.close()
 
 
-def test_tree_deeper_than_the_stack_falls_back_to_the_host_builder(rrt, oracle, monkeypatch):
+def _morton_chain_scene(rrt):
     """Morton codes 0, 1, 2, 4, 8, ... make the radix tree a chain of one level per code bit: 30 levels plus the 9 that
-    the 2048 coincident triangles of every cell add exceed the 37 the traversal stack holds.  The upload must notice
-    and build the scene with the depth-bounded host builder instead."""
+    the 2048 coincident triangles of every cell add exceed the 37 the traversal stack holds."""
     from rust_ray_tracer_amd import scenes
 
-    monkeypatch.setenv("RRT_DEVICE_BUILD_MIN", "2")
     s = rrt.Scene()
     m = s.add_material(rrt.Lambertian(0.5, 0.5, 0.5))
     cells = [(0, 0, 0), (1023, 1023, 1023)]
@@ -80,15 +78,52 @@ def test_tree_deeper_than_the_stack_falls_back_to_the_host_builder(rrt, oracle, 
         tris += [t] * 2048
     s.add_triangles(np.stack(tris), m)
     s.camera = rrt.Camera(1.0, 40.0, scenes.look_at_c2w((512.0, 512.0, 3000.0), (512.0, 512.0, 0.0)))
-    r = rrt.Renderer(device_build=True)
-    info = r.upload(s)
-    assert info.device_built == 0 and info.bvh_depth <= 37  # host-built after all
+    return s, cells
+
+
+def _check_chain_hits(r, s, cells, oracle):
     # a ray down the z axis from just above a cell's triangles hits the first of the coincident ones
     origins = np.float32([(cx + 0.5, cy + 0.4, cz + 0.9) for cx, cy, cz in cells])
     rays = helpers.make_rays(origins, np.tile(np.float32([0, 0, -1]), (len(cells), 1)))
     got = r.intersect(rays)
     helpers.assert_hits_match(got, oracle.OracleScene(s).intersect(rays))
     assert np.array_equal(got["prim_id"], 2048 * np.arange(len(cells)))
+
+
+def test_tree_deeper_than_the_stack_falls_back_to_the_host_builder(rrt, oracle, monkeypatch):
+    """The plain radix tree (RRT_LBVH_CLUSTER=0) of the Morton-chain scene is deeper than the traversal stack: the upload
+    must notice and build the scene with the depth-bounded host builder instead."""
+    monkeypatch.setenv("RRT_DEVICE_BUILD_MIN", "2")
+    monkeypatch.setenv("RRT_LBVH_CLUSTER", "0")
+    s, cells = _morton_chain_scene(rrt)
+    r = rrt.Renderer(device_build=True)
+    info = r.upload(s)
+    assert info.device_built == 0 and info.bvh_depth <= 37  # host-built after all
+    _check_chain_hits(r, s, cells, oracle)
+    r.close()
+
+
+def test_rebuilt_upper_levels_bound_the_depth_of_a_chain(rrt, oracle, monkeypatch):
+    """With the levels above the cut rebuilt by the host's builder (the default) the same scene stays on the GPU path:
+    the chain lies above the cut, and what replaces it is depth-bounded."""
+    monkeypatch.setenv("RRT_DEVICE_BUILD_MIN", "2")
+    s, cells = _morton_chain_scene(rrt)
+    r = rrt.Renderer(device_build=True)
+    info = r.upload(s)
+    assert info.device_built == 1 and info.bvh_depth <= 37
+    _check_chain_hits(r, s, cells, oracle)
+    host = rrt.Renderer()
+    host.upload(s)
+    o = oracle.OracleScene(s)
+    rays = np.concatenate([helpers.primary_rays(o, 256, 256, 4096, seed=3), helpers.bounce_rays(o, helpers.primary_rays(o, 256, 256, 2048, seed=4), seed=5)])
+    assert same_bits(r.intersect(rays), host.intersect(rays))
+    for cluster in ("2", "3", "7", "100000"):  # odd cut sizes; a cut above the whole tree keeps the radix tree (and falls back)
+        monkeypatch.setenv("RRT_LBVH_CLUSTER", cluster)
+        rr = rrt.Renderer(device_build=True)
+        rr.upload(s)
+        assert same_bits(rr.intersect(rays), host.intersect(rays)), cluster
+        rr.close()
+    host.close()
     r.close()
 
 
