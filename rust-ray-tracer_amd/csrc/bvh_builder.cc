@@ -214,10 +214,10 @@ struct Builder {
 }  // namespace
 
 BuildResult build_bvh(std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes, std::vector<uint32_t>& tri_order,
-                      uint32_t tri_base, uint32_t max_depth, unsigned threads) {
+                      uint32_t tri_base, uint32_t max_depth, unsigned threads, int64_t index_base) {
     BuildResult res;
     const uint32_t n = (uint32_t)prims.size();
-    const uint32_t node_base = (uint32_t)nodes.size();
+    const uint32_t node_base = index_base >= 0 ? (uint32_t)index_base : (uint32_t)nodes.size();
     Builder bld;
     bld.prims = prims.data();
     bld.local.resize(std::max<uint32_t>(n, 1u) + 1u);

@@ -27,12 +27,13 @@ struct BuildResult {
     float root_min[3], root_max[3];
 };
 
-// Builds a BVH over prims[0..n) and appends its nodes to `nodes` (indices in the produced nodes are
-// absolute, i.e. already offset by nodes.size() at entry).  Triangle primitives are emitted in leaf
+// Builds a BVH over prims[0..n) and appends its nodes to `nodes`.  Indices in the produced nodes are absolute: offset
+// by `index_base` (the index the first appended node will have in the scene's node array; negative: nodes.size() at
+// entry).  Triangle primitives are emitted in leaf
 // order into `tri_order` (append): a triangle leaf references tri_base + position in that order.
 // max_depth bounds the number of node levels (>= ceil(log2(n)) + 2 required).
 BuildResult build_bvh(std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes, std::vector<uint32_t>& tri_order,
-                      uint32_t tri_base, uint32_t max_depth, unsigned threads);
+                      uint32_t tri_base, uint32_t max_depth, unsigned threads, int64_t index_base = -1);
 
 }  // namespace rrt
 #endif

@@ -294,7 +294,7 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
     S.grid = hs.grid;
 
     c->info.prim_count = hs.prim_count;
-    c->info.node_count = (uint32_t)hs.nodes.size();
+    c->info.node_count = (uint32_t)hs.qnodes.size();
     c->info.tri_count = (uint32_t)hs.tris.size();
     c->info.bvh_depth = hs.depth;
     c->info.device_bytes = total;
@@ -315,7 +315,11 @@ rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
     const auto t0 = std::chrono::steady_clock::now();
     rrt_status st;
     try {
-        st = build_host_scene(scene, hs, err, build_threads());
+        // RRT_CHECK_DEVICE_MIN: the dry run defers BVHs of at least that many primitives, as an upload with the GPU
+        // builder would (times the host side of that path without a GPU)
+        uint32_t device_min = 0;
+        if (const char* e = std::getenv("RRT_CHECK_DEVICE_MIN")) device_min = (uint32_t)std::max(0, std::atoi(e));
+        st = build_host_scene(scene, hs, err, build_threads(), device_min);
     } catch (const std::bad_alloc&) {
         return set_err(nullptr, RRT_ERR_OOM, "rrt_scene_check: out of host memory while building the BVH");
     } catch (const std::exception& ex) {
@@ -324,7 +328,7 @@ rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
     if (st != RRT_OK) return set_err(nullptr, st, "rrt_scene_check: " + err);
     std::memset(out, 0, sizeof *out);
     out->prim_count = hs.prim_count;
-    out->node_count = (uint32_t)hs.nodes.size();
+    out->node_count = (uint32_t)hs.qnodes.size();
     out->tri_count = (uint32_t)hs.tris.size();
     out->bvh_depth = hs.depth;
     auto sz = [](size_t n, size_t rec) { return (uint64_t)(n ? n : 1) * rec; };

@@ -5,6 +5,9 @@
 #include <cfloat>
 #include <cmath>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -16,7 +19,7 @@ namespace {
 // Runs body(lo, hi) over [0, n) in contiguous pieces, on up to `threads` host threads when n is large.
 template <typename F>
 static void parallel_for(uint32_t n, unsigned threads, F body) {
-    const unsigned pieces = n >= (1u << 16) ? std::min<unsigned>(std::max(threads, 1u), 64u) : 1u;
+    const unsigned pieces = n >= (1u << 13) ? std::min<unsigned>(std::max(threads, 1u), 64u) : 1u;
     if (pieces <= 1u) {
         body(0u, n);
         return;
@@ -86,6 +89,15 @@ struct Expander {
     };
     bool expand(const rrt_object* objs, uint32_t n_objs, uint32_t& id, std::vector<BuildPrim>& prims,
                 const std::vector<MeshInfo>* meshes) {
+        {   // one growth of the big arrays instead of one per run (a scene may list its triangles in many runs)
+            size_t n_tris = 0, n_other = 0;
+            for (uint32_t oi = 0; oi < n_objs; ++oi) {
+                if (objs[oi].type == RRT_OBJ_TRIANGLES) n_tris += objs[oi].count;
+                else n_other += objs[oi].type == RRT_OBJ_CUBOIDS ? 6u * (size_t)objs[oi].count : objs[oi].count;
+            }
+            tri_src.reserve(tri_src.size() + n_tris);
+            prims.reserve(prims.size() + n_tris + n_other);
+        }
         for (uint32_t oi = 0; oi < n_objs; ++oi) {
             const rrt_object& ob = objs[oi];
             switch (ob.type) {
@@ -249,18 +261,21 @@ Grid make_grid(const float* mn, const float* mx) {
 
 namespace {
 
-// Appends the quantized form of hs.nodes[first..] (one BVH, root box [mn, mx]) to hs.qnodes.
-static Grid quantize_nodes(HostScene& hs, size_t first, const float* mn, const float* mx) {
+// Appends the quantized form of one BVH's nodes (builder output `built`, root box [mn, mx]) to hs.qnodes.
+static Grid quantize_nodes(HostScene& hs, const std::vector<BvhNode>& built, const float* mn, const float* mx, unsigned threads) {
     const Grid g = make_grid(mn, mx);
-    hs.qnodes.resize(hs.nodes.size());
-    for (size_t i = first; i < hs.nodes.size(); ++i) {
-        const BvhNode& n = hs.nodes[i];
-        QNode& q = hs.qnodes[i];
-        q.left = device_ref(n.left);
-        q.right = device_ref(n.right);
-        quantize_box(g, n.lmin, n.lmax, q.lbox);
-        quantize_box(g, n.rmin, n.rmax, q.rbox);
-    }
+    const size_t first = hs.qnodes.size();
+    hs.qnodes.resize(first + built.size());
+    parallel_for((uint32_t)built.size(), threads, [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t i = lo; i < hi; ++i) {
+            const BvhNode& n = built[i];
+            QNode& q = hs.qnodes[first + i];
+            q.left = device_ref(n.left);
+            q.right = device_ref(n.right);
+            quantize_box(g, n.lmin, n.lmax, q.lbox);
+            quantize_box(g, n.rmin, n.rmax, q.rbox);
+        }
+    });
     return g;
 }
 
@@ -268,34 +283,67 @@ static Grid quantize_nodes(HostScene& hs, size_t first, const float* mn, const f
 
 // Reserves nodes and triangle slots for a BVH the GPU will build; returns its root box in mn/mx.
 static void defer_build(HostScene& hs, std::vector<BuildPrim>& prims, std::vector<uint32_t>& tri_order, uint32_t budget,
-                        int mesh, float* mn, float* mx, int32_t& root, Grid& grid) {
+                        int mesh, float* mn, float* mx, int32_t& root, Grid& grid, unsigned threads) {
     DeferredBuild db;
-    db.node_base = (uint32_t)hs.nodes.size();
+    db.node_base = (uint32_t)hs.qnodes.size();
     db.tri_base = (uint32_t)tri_order.size();
     db.budget = budget;
     db.mesh = mesh;
+    // root box: per-piece boxes, then their union
+    const uint32_t n = (uint32_t)prims.size();
+    constexpr unsigned MAX_PIECES = 64;
+    float pmn[MAX_PIECES][3], pmx[MAX_PIECES][3];
+    for (unsigned k = 0; k < MAX_PIECES; ++k)
+        for (int a = 0; a < 3; ++a) { pmn[k][a] = FLT_MAX; pmx[k][a] = -FLT_MAX; }
+    std::atomic<unsigned> piece{0};
+    parallel_for(n, threads, [&](uint32_t lo, uint32_t hi) {
+        const unsigned k = piece.fetch_add(1) % MAX_PIECES;  // parallel_for never runs more than 64 pieces
+        float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t i = lo; i < hi; ++i)
+            for (int a = 0; a < 3; ++a) { lmn[a] = std::min(lmn[a], prims[i].bmin[a]); lmx[a] = std::max(lmx[a], prims[i].bmax[a]); }
+        for (int a = 0; a < 3; ++a) { pmn[k][a] = lmn[a]; pmx[k][a] = lmx[a]; }
+    });
     for (int a = 0; a < 3; ++a) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; }
+    for (unsigned k = 0; k < MAX_PIECES; ++k)
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], pmn[k][a]); mx[a] = std::max(mx[a], pmx[k][a]); }
+    // triangles keep their submission order (the GPU builder permutes the records itself); a triangle's `index`
+    // becomes its ordinal among this BVH's triangles
     uint32_t ordinal = 0;
+    const size_t order0 = tri_order.size();
+    size_t n_tris = 0;
+    for (const BuildPrim& p : prims) n_tris += p.kind == KIND_TRI ? 1u : 0u;
+    tri_order.resize(order0 + n_tris);
     for (BuildPrim& p : prims) {
-        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p.bmin[a]); mx[a] = std::max(mx[a], p.bmax[a]); }
         if (p.kind == KIND_TRI) {
-            tri_order.push_back(p.index);
+            tri_order[order0 + ordinal] = p.index;
             p.index = ordinal++;
         }
     }
     db.tri_count = ordinal;
     db.grid = grid = make_grid(mn, mx);
-    BvhNode blank;
+    QNode blank;
     std::memset(&blank, 0, sizeof blank);
-    hs.nodes.resize(hs.nodes.size() + prims.size(), blank);
-    hs.qnodes.resize(hs.nodes.size());
+    hs.qnodes.resize(hs.qnodes.size() + prims.size(), blank);  // the range the GPU builder fills (uploaded blank)
     root = (int32_t)db.node_base;  // the radix tree's root is its first inner node
     db.prims.swap(prims);
     hs.deferred.push_back(std::move(db));
 }
 
+// RRT_BUILD_TRACE=1: the phases of a scene build with their host times, on stderr.
+struct PhaseTrace {
+    bool on = std::getenv("RRT_BUILD_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rrt build] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string& err, unsigned threads,
                             uint32_t device_build_min) {
+    PhaseTrace trace;
     hs = HostScene();
     if (!d) { err = "scene is NULL"; return RRT_ERR_INVALID; }
     if (d->material_count == 0 || !d->materials) { err = "scene has no materials"; return RRT_ERR_INVALID; }
@@ -308,9 +356,23 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
 
     // scene scale -> conservative padding of every bounding box (beyond the reference's own 1e-4 pads)
     float scale = max_abs3(d->camera.origin);
-    for (uint32_t i = 0; i < d->triangle_count; ++i) {
-        const rrt_triangle& t = d->triangles[i];
-        scale = std::max(scale, std::max(max_abs3(t.v0), std::max(max_abs3(t.v1), max_abs3(t.v2))));
+    {
+        std::atomic<uint32_t> bits{0};  // max of non-negative floats == max of their bit patterns (+inf included)
+        parallel_for(d->triangle_count, threads, [&](uint32_t lo, uint32_t hi) {
+            float m = 0.f;
+            for (uint32_t i = lo; i < hi; ++i) {
+                const rrt_triangle& t = d->triangles[i];
+                m = std::max(m, std::max(max_abs3(t.v0), std::max(max_abs3(t.v1), max_abs3(t.v2))));
+            }
+            uint32_t b;
+            std::memcpy(&b, &m, 4);
+            uint32_t seen = bits.load();
+            while (b > seen && !bits.compare_exchange_weak(seen, b)) {}
+        });
+        const uint32_t b = bits.load();
+        float m;
+        std::memcpy(&m, &b, 4);
+        scale = std::max(scale, m);
     }
     for (uint32_t i = 0; i < d->sphere_count; ++i) {
         if (!std::isfinite(d->spheres[i].radius)) scale = INFINITY;
@@ -326,6 +388,7 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     for (uint32_t i = 0; i < d->instance_count; ++i) inst_scale = std::max(inst_scale, max_abs3(d->instances[i].offset));
     scale = scale * 1.5f + inst_scale;
     if (!(scale < 1e30f)) { err = "scene coordinates are not finite"; return RRT_ERR_INVALID; }
+    trace.mark("scene extent");
 
     Expander ex;
     ex.d = d;
@@ -374,14 +437,14 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         if (!ex.expand(d->mesh_objects + m.first_object, m.object_count, id, prims, nullptr)) return RRT_ERR_INVALID;
         const uint32_t budget = MAX_TREE_DEPTH - top_budget - 1u;
         if (device_build_min && prims.size() >= device_build_min) {
-            defer_build(hs, prims, tri_order, budget, (int)mi, meshes[mi].mn, meshes[mi].mx, meshes[mi].root, meshes[mi].grid);
+            defer_build(hs, prims, tri_order, budget, (int)mi, meshes[mi].mn, meshes[mi].mx, meshes[mi].root, meshes[mi].grid, threads);
             meshes[mi].prim_count = id;
             meshes[mi].depth = 0;
             continue;
         }
-        const size_t first_node = hs.nodes.size();
-        BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), budget, threads);
-        meshes[mi].grid = quantize_nodes(hs, first_node, br.root_min, br.root_max);
+        std::vector<BvhNode> built;
+        BuildResult br = build_bvh(prims, built, tri_order, (uint32_t)tri_order.size(), budget, threads, (int64_t)hs.qnodes.size());
+        meshes[mi].grid = quantize_nodes(hs, built, br.root_min, br.root_max, threads);
         if (br.depth > budget) { err = "mesh too large for the traversal stack of an instanced scene"; return RRT_ERR_INVALID; }
         meshes[mi].root = br.root;
         meshes[mi].prim_count = id;
@@ -391,20 +454,22 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         deepest_mesh = std::max(deepest_mesh, br.depth);
     }
 
+    trace.mark("meshes");
     std::vector<BuildPrim> prims;
     uint32_t id = 0;
     if (!ex.expand(d->world, d->world_count, id, prims, &meshes)) return RRT_ERR_INVALID;
+    trace.mark("world list expanded");
     hs.prim_count = id;
     hs.deepest_mesh = deepest_mesh;
     if (device_build_min && prims.size() >= device_build_min) {
         float mn[3], mx[3];
-        defer_build(hs, prims, tri_order, top_budget, -1, mn, mx, hs.root, hs.grid);
+        defer_build(hs, prims, tri_order, top_budget, -1, mn, mx, hs.root, hs.grid, threads);
         hs.top_depth = 0;
         hs.depth = 0;
     } else {
-        const size_t first_node = hs.nodes.size();
-        BuildResult br = build_bvh(prims, hs.nodes, tri_order, (uint32_t)tri_order.size(), top_budget, threads);
-        hs.grid = quantize_nodes(hs, first_node, br.root_min, br.root_max);
+        std::vector<BvhNode> built;
+        BuildResult br = build_bvh(prims, built, tri_order, (uint32_t)tri_order.size(), top_budget, threads, (int64_t)hs.qnodes.size());
+        hs.grid = quantize_nodes(hs, built, br.root_min, br.root_max, threads);
         if (br.depth + (hs.insts.empty() ? 0u : deepest_mesh + 1u) > MAX_TREE_DEPTH) {
             err = "scene too deep for the traversal stack";
             return RRT_ERR_INVALID;
@@ -413,15 +478,17 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         hs.top_depth = br.depth;
         hs.depth = br.depth + (hs.insts.empty() ? 0u : deepest_mesh);
     }
+    trace.mark("top-level BVH (or deferral)");
     hs.has_instances = !hs.insts.empty();
     if (tri_order.size() > REF_OFFSET_MASK) { err = "too many triangles"; return RRT_ERR_INVALID; }
-    if (hs.nodes.size() > (size_t)REF_OFFSET_MASK) { err = "too many BVH nodes"; return RRT_ERR_INVALID; }  // device_ref: byte offsets below 2^30
+    if (hs.qnodes.size() > (size_t)REF_OFFSET_MASK) { err = "too many BVH nodes"; return RRT_ERR_INVALID; }  // device_ref: byte offsets below 2^30
 
     hs.tris.resize(tri_order.size());
     parallel_for((uint32_t)tri_order.size(), threads, [&](uint32_t lo, uint32_t hi) {
         for (uint32_t k = lo; k < hi; ++k) hs.tris[k] = ex.tri_src[tri_order[k]];
     });
 
+    trace.mark("triangle records in leaf order");
     const rrt_camera& c = d->camera;
     for (int a = 0; a < 3; ++a) {
         hs.cam.c0[a] = c.c2w[a]; hs.cam.c1[a] = c.c2w[3 + a]; hs.cam.c2[a] = c.c2w[6 + a]; hs.cam.tr[a] = c.c2w[9 + a];

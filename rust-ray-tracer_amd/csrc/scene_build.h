@@ -24,8 +24,7 @@ struct DeferredBuild {
 };
 
 struct HostScene {
-    std::vector<BvhNode> nodes;   // builder output (full-precision boxes), host only
-    std::vector<QNode> qnodes;    // the same nodes on their BVH's 16-bit grid: what is uploaded
+    std::vector<QNode> qnodes;    // every BVH's nodes on its 16-bit grid: what is uploaded (ranges left to the GPU builder stay blank)
     Grid grid{};                  // grid of the top-level BVH
     std::vector<TriRec> tris;
     std::vector<SphereRec> spheres;
