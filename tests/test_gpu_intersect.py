@@ -236,3 +236,53 @@ def test_random_soups_with_hostile_coordinates(rrt, oracle, monkeypatch, device_
         assert (want["prim_id"] >= 0).mean() > 0.02, (scale, offset, flat_axis)  # (tiny triangles fail the reference's det > 1e-5)
         helpers.assert_hits_match(got, want)
         r.close()
+
+
+def test_scene_fed_to_both_sides_is_itself_checked_on_the_box(rrt, oracle):
+    """The oracle and the GPU path both consume the scene the product's glTF loader emits, so a loader error would be
+    invisible to the comparisons above.  Here the loader's triangles are compared, on the box that runs the GPU
+    gates, with an independent reading of the same file (json + base64 + numpy, following reference src/gltf.rs:118-244),
+    and that independent scene -- built without the loader -- must give the same closest hits as the loaded one."""
+    import base64
+    import json
+    import os
+
+    path = os.path.join(helpers.ASSETS, "suzanne.gltf")
+    d = json.load(open(path))
+    bufs = [base64.b64decode(b["uri"].split(",")[1]) for b in d["buffers"]]
+    views = [bufs[v["buffer"]][v["byteOffset"]:v["byteOffset"] + v["byteLength"]] for v in d["bufferViews"]]
+    tris = []
+    for mesh in d["meshes"]:
+        p = mesh["primitives"][0]
+        ia, pa = d["accessors"][p["indices"]], d["accessors"][p["attributes"]["POSITION"]]
+        idx = np.frombuffer(views[ia["bufferView"]], np.uint16, ia["count"]).astype(np.int64)
+        pos = np.frombuffer(views[pa["bufferView"]], np.float32, pa["count"] * 3).reshape(-1, 3)
+        tris.append(pos[idx[:3 * (len(idx) // 3)]].reshape(-1, 3, 3))
+    want = np.concatenate(tris)
+    loaded = helpers.scene_suzanne(rrt)
+    t = np.concatenate(loaded._tri_chunks)
+    assert np.array_equal(np.stack([t["v0"], t["v1"], t["v2"]], 1), want)
+    # the same scene assembled by hand: triangles from the independent reading, light and camera as documented
+    # (reference src/gltf.rs:287-299: radius 0.2 emissive sphere at the light node's translation)
+    s = rrt.Scene()
+    m = s.add_material(loaded.materials[0])
+    s.add_triangles(want, m)
+    lm = s.add_material(loaded.materials[loaded.spheres[0][2]])
+    s.add_sphere(loaded.spheres[0][0], 0.2, lm)
+    s.add_sphere_light(loaded.spheres[0][0], 0.2)
+    s.camera = loaded.camera
+    s.background = (0.051, 0.051, 0.051)
+    assert abs(loaded.spheres[0][0][0] - 4.076245) < 1e-5 and abs(loaded.spheres[0][1] - 0.2) < 1e-7
+    a, b = rrt.Renderer(seed=3), rrt.Renderer(seed=3)
+    a.upload(loaded)
+    b.upload(s)
+    o = oracle.OracleScene(s)
+    rays = np.concatenate(list(helpers.ray_suite(s, o, n=2048, seed=41).values()))
+    ha, hb = a.intersect(rays), b.intersect(rays)
+    assert ha.tobytes() == hb.tobytes()
+    helpers.assert_hits_match(hb, o.intersect(rays))
+    ia, _ = a.render(96, 54, 4)
+    ib, _ = b.render(96, 54, 4)
+    assert np.array_equal(ia, ib)
+    a.close()
+    b.close()
