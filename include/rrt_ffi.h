@@ -66,6 +66,11 @@ typedef struct rrt_config {
 #define RRT_CFG_DEVICE_BUILD 2u /* build large BVHs (>= 4096 primitives) on the GPU: a linear BVH over Morton-sorted
                                  * primitives instead of the host's SAH build (reference src/geometry/mod.rs:161-199 is
                                  * the step it replaces).  Faster to build, slower to traverse; results are identical. */
+#define RRT_CFG_NO_UNROLL 4u    /* keep instanced meshes as a two-level BVH.  Default: when every instanced mesh holds
+                                 * triangles only and the copies fit a node budget, each instance (reference
+                                 * src/geometry/transform.rs:9-12,44-49) is written out as a world-space copy of its mesh's
+                                 * tree inside the one top-level BVH; the ray changes space at the triangle test only,
+                                 * on the mesh's shared object-space records.  Same hits, faster walk, more node memory. */
 
 /* ---- scene description: the reference's scene/material types as POD ---- */
 
@@ -206,7 +211,7 @@ typedef struct rrt_scene_info {
     float build_ms;          /* BVH build (host, plus the GPU builder where it ran)       */
     float upload_ms;
     uint32_t device_built;   /* number of BVHs the GPU builder built                      */
-    uint32_t reserved;
+    uint32_t unrolled_instances; /* instances written out into the top-level BVH (0: none, or RRT_CFG_NO_UNROLL) */
 } rrt_scene_info;
 
 /* ---- lifetime ----  replaces: process start-up in reference src/main.rs:26-56 */

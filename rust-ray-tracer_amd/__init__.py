@@ -32,6 +32,7 @@ LIGHT_SPHERE, LIGHT_XZRECT, LIGHT_OTHER = 0, 1, 2
 RECT_FLIP_FACE = 1
 CFG_COUNT_VISITS = 1
 CFG_DEVICE_BUILD = 2
+CFG_NO_UNROLL = 4
 GLTF_COMPAT, GLTF_EXTENDED = 0, 1
 
 
@@ -125,7 +126,7 @@ class Stats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("prim_count", C.c_uint32), ("node_count", C.c_uint32), ("tri_count", C.c_uint32),
                 ("bvh_depth", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
-                ("upload_ms", C.c_float), ("device_built", C.c_uint32), ("reserved", C.c_uint32)]
+                ("upload_ms", C.c_float), ("device_built", C.c_uint32), ("unrolled_instances", C.c_uint32)]
 
 
 class GltfOptions(C.Structure):
@@ -478,10 +479,11 @@ class Renderer:
     ``get_color`` + ``put_pixel`` (src/vec3.rs:30-53, src/main.rs:104-109)."""
 
     def __init__(self, device: int = 0, seed: int = 1, max_depth: int = 4, t_min: float = 1e-4, count_visits: bool = False,
-                 device_build: bool = False):
+                 device_build: bool = False, unroll_instances: bool = True):
         self.lib = load_library()
         cfg = Config(device, seed, max_depth, t_min,
-                     (CFG_COUNT_VISITS if count_visits else 0) | (CFG_DEVICE_BUILD if device_build else 0))
+                     (CFG_COUNT_VISITS if count_visits else 0) | (CFG_DEVICE_BUILD if device_build else 0) |
+                     (0 if unroll_instances else CFG_NO_UNROLL))
         self.ctx = C.c_void_p()
         _check(self.lib.rrt_create(C.byref(cfg), C.byref(self.ctx)), None)
         self._scene_keep = None
@@ -500,6 +502,9 @@ class Renderer:
     def upload(self, scene: Scene) -> SceneInfo:
         d = scene.desc()
         _check(self.lib.rrt_scene_upload(self.ctx, C.byref(d)), self.ctx)
+        return self.info()
+
+    def info(self) -> SceneInfo:
         info = SceneInfo()
         _check(self.lib.rrt_scene_get_info(self.ctx, C.byref(info)), self.ctx)
         return info
@@ -554,10 +559,11 @@ class RendererGroup:
     accumulation buffers are summed on member 0.  Stands for the reference's rayon pool (``src/main.rs:42-49,86``)."""
 
     def __init__(self, devices: Sequence[int], seed: int = 1, max_depth: int = 4, t_min: float = 1e-4,
-                 count_visits: bool = False, device_build: bool = False):
+                 count_visits: bool = False, device_build: bool = False, unroll_instances: bool = True):
         self.lib = load_library()
         cfg = Config(0, seed, max_depth, t_min,
-                     (CFG_COUNT_VISITS if count_visits else 0) | (CFG_DEVICE_BUILD if device_build else 0))
+                     (CFG_COUNT_VISITS if count_visits else 0) | (CFG_DEVICE_BUILD if device_build else 0) |
+                     (0 if unroll_instances else CFG_NO_UNROLL))
         devs = (C.c_int32 * len(devices))(*devices)
         self.grp = C.c_void_p()
         _check(self.lib.rrt_group_create(C.byref(cfg), devs, len(devices), C.byref(self.grp)), None)

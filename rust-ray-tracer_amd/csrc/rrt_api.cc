@@ -92,6 +92,16 @@ void free_scene(rrt_ctx* c) {
     c->has_scene = false;
 }
 
+// The instance records as the device holds them: an identity record in front (SceneDev::insts points behind it), which
+// is what a triangle outside every instance reads in an unrolled scene.
+std::vector<InstRec> insts_with_identity(const std::vector<InstRec>& insts) {
+    std::vector<InstRec> v(insts.size() + 1u);
+    std::memset(&v[0], 0, sizeof(InstRec));
+    v[0].cos_t = 1.0f;
+    std::copy(insts.begin(), insts.end(), v.begin() + 1);
+    return v;
+}
+
 template <typename T>
 rrt_status upload(rrt_ctx* c, const std::vector<T>& v, void** dst, uint64_t& total) {
     // every array gets at least one record so that kernels never see a NULL base
@@ -123,6 +133,14 @@ rrt_status stage(rrt_ctx* c, int slot, size_t bytes, void** out) {
 rrt_status order_after_pending(rrt_ctx* c, hipStream_t s) {
     if (c->render_pending && s != c->last_stream) RRT_HIP(c, hipStreamWaitEvent(s, c->ev_stop, 0));
     return RRT_OK;
+}
+
+// Instances are unrolled into the top-level BVH unless the context (RRT_CFG_NO_UNROLL) or the environment
+// (RRT_UNROLL_INSTANCES=0, an experiment knob) says otherwise.
+bool unroll_wanted(uint32_t cfg_flags) {
+    if (cfg_flags & RRT_CFG_NO_UNROLL) return false;
+    const char* e = std::getenv("RRT_UNROLL_INSTANCES");
+    return !(e && std::atoi(e) == 0);
 }
 
 unsigned build_threads() {
@@ -219,7 +237,7 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
         const auto t0 = std::chrono::steady_clock::now();
         if (!prebuilt) {
             try {
-                st = build_host_scene(scene, hs, err, build_threads(), device_min);
+                st = build_host_scene(scene, hs, err, build_threads(), device_min, unroll_wanted(c->cfg.flags));
             } catch (const std::bad_alloc&) {
                 return set_err(c, RRT_ERR_OOM, "rrt_scene_upload: out of host memory while building the BVH");
             } catch (const std::exception& ex) {
@@ -234,7 +252,7 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
         total = 0;
         if ((st = upload(c, hs.qnodes, &c->d_nodes, total)) != RRT_OK || (st = upload(c, hs.tris, &c->d_tris, total)) != RRT_OK ||
             (st = upload(c, hs.spheres, &c->d_spheres, total)) != RRT_OK || (st = upload(c, hs.rects, &c->d_rects, total)) != RRT_OK ||
-            (st = upload(c, hs.insts, &c->d_insts, total)) != RRT_OK || (st = upload(c, hs.mats, &c->d_mats, total)) != RRT_OK ||
+            (st = upload(c, insts_with_identity(hs.insts), &c->d_insts, total)) != RRT_OK || (st = upload(c, hs.mats, &c->d_mats, total)) != RRT_OK ||
             (st = upload(c, hs.lights, &c->d_lights, total)) != RRT_OK) {
             free_scene(c);
             return st;
@@ -262,7 +280,7 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
             if (db.mesh < 0) hs.top_depth = r.depth;
             else hs.deepest_mesh = std::max(hs.deepest_mesh, r.depth);
         }
-        if (fits && hs.top_depth + (hs.has_instances ? hs.deepest_mesh + 1u : 0u) > MAX_TREE_DEPTH) fits = false;
+        if (fits && hs.top_depth + ((hs.has_instances || hs.unroll_shift) ? hs.deepest_mesh + 1u : 0u) > MAX_TREE_DEPTH) fits = false;
         const auto t3 = std::chrono::steady_clock::now();
         build_ms += std::chrono::duration<float, std::milli>(t1 - t0).count() + std::chrono::duration<float, std::milli>(t3 - t2).count();
         upload_ms += std::chrono::duration<float, std::milli>(t2 - t1).count();
@@ -274,16 +292,17 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
         }
         device_min = 0;
     }
-    hs.depth = hs.top_depth + (hs.has_instances ? hs.deepest_mesh : 0u);
+    hs.depth = hs.top_depth + ((hs.has_instances || hs.unroll_shift) ? hs.deepest_mesh : 0u);
     c->info.device_built = (uint32_t)hs.deferred.size();
 
     SceneDev& S = c->sdev;
     S.nodes = (const QNode*)c->d_nodes; S.tris = (const TriRec*)c->d_tris; S.spheres = (const SphereRec*)c->d_spheres;
-    S.rects = (const RectRec*)c->d_rects; S.insts = (const InstRec*)c->d_insts; S.mats = (const MatRec*)c->d_mats;
+    S.rects = (const RectRec*)c->d_rects; S.insts = (const InstRec*)c->d_insts + 1; S.mats = (const MatRec*)c->d_mats;
     S.lights = (const LightRec*)c->d_lights;
     S.light_count = (uint32_t)hs.lights.size();
     S.root = device_ref(hs.root);
     S.has_instances = hs.has_instances ? 1u : 0u;
+    S.unroll_shift = hs.unroll_shift;
     S.light_weight = S.light_count ? 1.0f / (float)S.light_count : 0.0f;
     S.light_zone = S.light_count ? (uint32_t)((0x100000000ull) % S.light_count) : 0u;
     S.cam = hs.cam;
@@ -297,6 +316,7 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
     c->info.node_count = (uint32_t)hs.qnodes.size();
     c->info.tri_count = (uint32_t)hs.tris.size();
     c->info.bvh_depth = hs.depth;
+    c->info.unrolled_instances = hs.unrolled_instances;
     c->info.device_bytes = total;
     c->info.build_ms = build_ms;
     c->info.upload_ms = upload_ms;
@@ -319,7 +339,7 @@ rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
         // builder would (times the host side of that path without a GPU)
         uint32_t device_min = 0;
         if (const char* e = std::getenv("RRT_CHECK_DEVICE_MIN")) device_min = (uint32_t)std::max(0, std::atoi(e));
-        st = build_host_scene(scene, hs, err, build_threads(), device_min);
+        st = build_host_scene(scene, hs, err, build_threads(), device_min, unroll_wanted(0u));
     } catch (const std::bad_alloc&) {
         return set_err(nullptr, RRT_ERR_OOM, "rrt_scene_check: out of host memory while building the BVH");
     } catch (const std::exception& ex) {
@@ -331,9 +351,10 @@ rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
     out->node_count = (uint32_t)hs.qnodes.size();
     out->tri_count = (uint32_t)hs.tris.size();
     out->bvh_depth = hs.depth;
+    out->unrolled_instances = hs.unrolled_instances;
     auto sz = [](size_t n, size_t rec) { return (uint64_t)(n ? n : 1) * rec; };
     out->device_bytes = sz(hs.qnodes.size(), sizeof(QNode)) + sz(hs.tris.size(), sizeof(TriRec)) + sz(hs.spheres.size(), sizeof(SphereRec)) +
-                        sz(hs.rects.size(), sizeof(RectRec)) + sz(hs.insts.size(), sizeof(InstRec)) + sz(hs.mats.size(), sizeof(MatRec)) +
+                        sz(hs.rects.size(), sizeof(RectRec)) + sz(hs.insts.size() + 1u, sizeof(InstRec)) + sz(hs.mats.size(), sizeof(MatRec)) +
                         sz(hs.lights.size(), sizeof(LightRec));
     out->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return RRT_OK;
@@ -732,7 +753,7 @@ rrt_status rrt_group_scene_upload(rrt_group* g, const rrt_scene_desc* scene) {
         rrt_status st;
         const auto t0 = std::chrono::steady_clock::now();
         try {
-            st = build_host_scene(scene, hs, err, build_threads(), 0u);
+            st = build_host_scene(scene, hs, err, build_threads(), 0u, unroll_wanted(g->members[0]->cfg.flags));
         } catch (const std::bad_alloc&) {
             return group_err(g, RRT_ERR_OOM, "rrt_group_scene_upload: out of host memory while building the BVH");
         } catch (const std::exception& ex) {

@@ -323,6 +323,18 @@ __device__ __forceinline__ bool first_active_lane() {
 // and never a flat access through a generic pointer.
 typedef __attribute__((address_space(3))) int lds_int;
 
+// How a kernel meets instanced meshes (template parameter MODE of the traversal functions):
+//   MODE_FLAT       the scene has no instances: one BVH.
+//   MODE_TWO_LEVEL  instance leaves in the top-level BVH; a lane that reaches one changes its ray's space and walks the
+//                   mesh's own BVH (reference src/geometry/transform.rs:22-31,99-130 as it stands).
+//   MODE_UNROLLED   every instance's copy of its mesh's BVH is part of ONE tree whose boxes are all in world space; the
+//                   change of space happens at the triangle test only: a triangle leaf's reference carries the instance
+//                   (slot << S.unroll_shift | first record, slot 0 = not instanced), the lane transforms its ray with that
+//                   instance's record (S.insts[slot - 1]; S.insts[-1] is an identity record) and runs the reference's
+//                   test on the mesh's object-space triangle record.  Same primitive tests on the same operands as
+//                   the two-level walk, so the same hits; no markers, no second grid, no parked rays.
+static constexpr int MODE_FLAT = 0, MODE_TWO_LEVEL = 1, MODE_UNROLLED = 2;
+
 // Resumable traversal state of one lane.  The render kernel interleaves traversal with shading of the lanes
 // that have finished, so a ray's walk can be suspended between any two steps.
 struct Trav {
@@ -386,7 +398,7 @@ __device__ __forceinline__ void slab_pair(uint32_t w, uint32_t rot, float a, flo
     t_out = __builtin_fmaf((float)(v >> 16), a, b);
 }
 
-template <bool INST>
+template <int MODE>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, lds_int* stack, int stride, Trav& T) {
     T.best.t = tmax; T.best.id = 0xFFFFFFFFu; T.best.u = 0.f; T.best.v = 0.f; T.best.what = 0u; T.best.inst = -1;
     trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
@@ -409,10 +421,11 @@ __device__ __forceinline__ bool trav_due(int cur) { return (uint32_t)cur - (REF_
 // the few lanes that need it.  `o`, `d`: the lane's ray in the space it is walking (only touched when INST: replaced
 // by the object-space ray on entering an instance and by the parked world-space ray on leaving it); `wray`: the lane's
 // slot of the parked world rays (INST only).
-template <bool INST, bool COUNT, int K = 0, int STEPS = 1>
+template <int MODE, bool COUNT, int K = 0, int STEPS = 1>
 __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, float tmin, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes, lds_int* lim = nullptr, int* deep = nullptr,
                                            lds_float* wray = nullptr) {
+    constexpr bool INST = MODE == MODE_TWO_LEVEL;
     V3 ga = T.ga, gb = T.gb;
     // rotate count of a node's plane pair: 16 where the ray runs against the axis (the sign of ga, the grid step
     // being positive), else 0
@@ -549,20 +562,39 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
 // One primitive per step keeps the cost of a pass the same for every lane, whatever its leaf holds.
 // Precondition: T.cur is negative and not REF_DONE.
 // PAIR: a triangle leaf with at least two records left has two of them tested in one step.
-template <bool INST, bool COUNT, int K = 0, bool PAIR = false>
+template <int MODE, bool COUNT, int K = 0, bool PAIR = false>
 __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float tmin, int stride, Trav& T,
                                           TraceCounters& cnt, lds_int* lim = nullptr, int* deep = nullptr,
                                           lds_float* wray = nullptr) {
+    constexpr bool INST = MODE == MODE_TWO_LEVEL;
     const uint32_t ref = (uint32_t)T.cur;
     const uint32_t kind = (ref >> 28) & 7u;
-    const uint32_t first = ref & REF_OFFSET_MASK;
-    const V3 ro = o, rd = d;  // the ray in the space being walked
-    const InstRec* insts = INST ? S.insts : nullptr;
+    uint32_t first = ref & REF_OFFSET_MASK;
+    V3 ro = o, rd = d;  // the ray in the space being walked
+    const InstRec* insts = MODE != MODE_FLAT ? S.insts : nullptr;
+    int32_t tri_inst = T.cur_inst;  // instance a triangle of this leaf belongs to
+    uint32_t first_mask = REF_OFFSET_MASK;
+    if (MODE == MODE_UNROLLED) {
+        // a triangle leaf names its instance: the ray goes into that instance's space for the test, exactly as
+        // Translate::hit and RotateY::hit move it (transform.rs:24,101-108); slot 0 (inst -1) reads the identity
+        // record in front of the array and keeps the ray as it is
+        first_mask = (1u << S.unroll_shift) - 1u;
+        tri_inst = kind == KIND_TRI ? (int32_t)(first >> S.unroll_shift) - 1 : -1;
+        first &= kind == KIND_TRI ? first_mask : REF_OFFSET_MASK;
+        const float4 x0 = reinterpret_cast<const float4*>(&S.insts[tri_inst])[0];
+        const float4 x1 = reinterpret_cast<const float4*>(&S.insts[tri_inst])[1];
+        const V3 m = o - v3(x0.x, x0.y, x0.z);
+        const V3 to = v3(x1.y * m.x - x1.x * m.z, m.y, x1.x * m.x + x1.y * m.z);
+        const V3 td = v3(x1.y * d.x - x1.x * d.z, d.y, x1.x * d.x + x1.y * d.z);
+        const bool in_inst = tri_inst >= 0;
+        ro = v3(in_inst ? to.x : o.x, in_inst ? to.y : o.y, in_inst ? to.z : o.z);
+        rd = v3(in_inst ? td.x : d.x, in_inst ? td.y : d.y, in_inst ? td.z : d.z);
+    }
     // The common case, decided once for the wavefront: every lane of the pass is at a triangle and the entry below
     // its stack top is in LDS.  The step then ends without a branch: the entry below the top is read in any case and
     // becomes current, and the top moves down, only if the leaf has no triangle left.
     if (__builtin_expect(__ballot(kind != KIND_TRI || (K > 0 && T.top - stride >= lim)) == 0ull, 1)) {
-        test_triangle(S.tris, first, ro, rd, tmin, insts, T.cur_inst, T.best);
+        test_triangle(S.tris, first, ro, rd, tmin, insts, tri_inst, T.best);
         if (COUNT) {
             cnt.prims++;
             if (first_active_lane()) cnt.wave_prims++;
@@ -575,7 +607,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
         bool more = ((r >> 25) & 7u) != 0u;
         if (PAIR && more) {
             r += 1u - (1u << 25);  // next record, one triangle fewer
-            test_triangle(S.tris, r & REF_OFFSET_MASK, ro, rd, tmin, insts, T.cur_inst, T.best);
+            test_triangle(S.tris, r & first_mask, ro, rd, tmin, insts, tri_inst, T.best);
             if (COUNT) {
                 cnt.prims++;
                 if (first_active_lane()) cnt.wave_prims++;
@@ -589,7 +621,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
         return;
     }
     if (kind == KIND_TRI) {
-        test_triangle(S.tris, first, ro, rd, tmin, insts, T.cur_inst, T.best);
+        test_triangle(S.tris, first, ro, rd, tmin, insts, tri_inst, T.best);
         if (COUNT) {
             cnt.prims++;
             if (first_active_lane()) cnt.wave_prims++;
@@ -622,14 +654,14 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
 }
 
 // Complete walk of one ray (used by the ray-batch kernel): the same passes as the render kernel, run to the end.
-template <bool INST, bool COUNT>
+template <int MODE, bool COUNT>
 __device__ __forceinline__ void trace(const SceneDev& S, V3 o, V3 d, float tmin, float tmax, lds_int* stack, int stride,
                                       Best& best, TraceCounters& cnt, lds_float* wray = nullptr) {
     Trav T;
-    trav_begin<INST>(S, o, d, tmax, stack, stride, T);
+    trav_begin<MODE>(S, o, d, tmax, stack, stride, T);
     while (T.cur != REF_DONE) {
-        trav_nodes<INST, COUNT>(S, o, d, tmin, stride, T, cnt, 0u, nullptr, nullptr, wray);  // 0: descend until this lane is at a leaf
-        if (T.cur != REF_DONE) trav_leaf<INST, COUNT>(S, o, d, tmin, stride, T, cnt, nullptr, nullptr, wray);
+        trav_nodes<MODE, COUNT>(S, o, d, tmin, stride, T, cnt, 0u, nullptr, nullptr, wray);  // 0: descend until this lane is at a leaf
+        if (T.cur != REF_DONE) trav_leaf<MODE, COUNT>(S, o, d, tmin, stride, T, cnt, nullptr, nullptr, wray);
     }
     best = T.best;
 }

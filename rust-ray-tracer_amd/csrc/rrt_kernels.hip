@@ -56,10 +56,11 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
     return (uint32_t)(((unsigned long long)q * n_work) / N_QUEUES);
 }
 
-template <bool INST, bool COUNT, bool PIPELINED>
-__global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 7 : 6)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+template <int MODE, bool COUNT, bool PIPELINED>
+__global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? 7 : 6)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
+    constexpr bool INST = MODE == MODE_TWO_LEVEL;
     // RENDER_STACK entries per lane of the traversal stack live in LDS, the rest in private memory (six workgroups per
     // CU, seven in the pipelined form, whose large scenes gain more from the extra wavefront than they lose to its
     // spills).  Instanced scenes add six floats per lane for the world-space ray of a lane that walks inside a mesh.
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 
                 camera_ray(S.cam, u, v, width, height, o, d);
                 beta = v3(1.f, 1.f, 1.f);
                 depth = S.max_depth;
-                trav_begin<INST>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                trav_begin<MODE>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
             }
 
             for (;;) {
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
                             const uint32_t nodes0 = cnt.nodes;
-                            trav_nodes<INST, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                            trav_nodes<MODE, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                             uint32_t steps = cnt.nodes - nodes0;
                             for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                             if (lane == 0u) {
@@ -169,10 +170,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 
                                 slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                             }
                         } else {
-                            trav_nodes<INST, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                            trav_nodes<MODE, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         }
                     }
-                    if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<INST, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray);
+                    if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray);
                 }
                 // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
                 if (has_ray && T.cur == REF_DONE) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 
                             has_ray = false;
                         }
                     }
-                    if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                    if (has_ray) trav_begin<MODE>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
                 }
                 if (__ballot(has_ray) == 0ull) break;  // every lane has rendered all samples of this item
             }
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<INST, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                         if (lane == 0u) {
@@ -307,10 +308,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 
                             slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                         }
                     } else {
-                        trav_nodes<INST, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                     }
                 }
-                if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<INST, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray);
+                if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray);
             }
 
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? RRT_INST_WAVES : (PIPELINED ? 
                         has_ray = true;
                     }
                 }
-                if (has_ray) trav_begin<INST>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                if (has_ray) trav_begin<MODE>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
             }
         }
     }
@@ -430,9 +431,10 @@ __device__ __forceinline__ rrt_hit hit_record(const SceneDev& S, const Best& bes
 
 // Closest hit for a batch of rays, one lane per ray from start to end (kept as the plain form of the walk; the
 // streaming kernel below is the one the library launches).
-template <bool INST>
+template <int MODE>
 __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* __restrict__ rays, size_t n, float tmin,
                                                     float tmax, rrt_hit* __restrict__ out) {
+    constexpr bool INST = MODE == MODE_TWO_LEVEL;
     __shared__ int s_stack[STACK_DEPTH * WAVE];
     __shared__ float s_wray[INST ? 6 * WAVE : 1];
     const size_t i = (size_t)blockIdx.x * WAVE + threadIdx.x;
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* _
     const V3 d = v3(r.direction[0], r.direction[1], r.direction[2]);
     Best best;
     TraceCounters cnt = {0u, 0u, 0u, 0u, 0u};
-    trace<INST, false>(S, o, d, tmin, tmax, (lds_int*)(s_stack + threadIdx.x), WAVE, best, cnt,
+    trace<MODE, false>(S, o, d, tmin, tmax, (lds_int*)(s_stack + threadIdx.x), WAVE, best, cnt,
                        INST ? (lds_float*)(s_wray + threadIdx.x) : nullptr);
     out[i] = hit_record(S, best, o, d);
 }
@@ -454,16 +456,32 @@ __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* _
 // about 10 ns per add, which would otherwise bound the kernel); whenever at least `refill_min` lanes of a
 // wavefront are idle, they take the next indices of the wavefront's block.  counters (COUNT only): {-, node visits, primitive tests, node passes, primitive
 // passes, -, refill passes}.
-// (Instanced scenes: the parked world rays bring the workgroup's LDS to 45 KB, three workgroups per CU.)
-template <bool INST, bool COUNT>
-__global__ __launch_bounds__(RENDER_BLOCK, INST ? 3 : 4) void k_trace_stream(SceneDev S, const rrt_ray* __restrict__ rays, uint32_t n,
+// The streaming kernel keeps the bottom RRT_STREAM_K stack entries of a lane in LDS and the rest in private memory, like
+// the render kernel: with the whole 39-entry stack in LDS a CU held four workgroups, and the walk is a chain of
+// dependent loads that four wavefronts per SIMD do not cover (tile-ordered primary rays of the 1M-triangle scene:
+// 10.3 Grays/s at four wavefronts, 12.6 at seven; 134M-ray batches, where the tail no longer shows: 14.2).
+#ifndef RRT_STREAM_K
+#define RRT_STREAM_K 16
+#endif
+#ifndef RRT_STREAM_WAVES
+#define RRT_STREAM_WAVES 7
+#endif
+#ifndef RRT_STREAM_WAVES_INST
+#define RRT_STREAM_WAVES_INST 6
+#endif
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_STREAM_WAVES_INST : RRT_STREAM_WAVES) void k_trace_stream(SceneDev S, const rrt_ray* __restrict__ rays, uint32_t n,
                                                                   float tmin, float tmax, rrt_hit* __restrict__ out,
                                                                   unsigned int* __restrict__ head, uint32_t refill_min,
                                                                   uint32_t node_share_64ths,
                                                                   unsigned long long* __restrict__ counters) {
-    __shared__ int s_stack[STACK_DEPTH * RENDER_BLOCK];
+    constexpr bool INST = MODE == MODE_TWO_LEVEL;
+    constexpr int K = RRT_STREAM_K;
+    __shared__ int s_stack[(K > 0 ? K : STACK_DEPTH) * RENDER_BLOCK];
     __shared__ float s_wray[INST ? 6 * RENDER_BLOCK : 1];
     lds_int* stack = (lds_int*)(s_stack + threadIdx.x);
+    lds_int* lim = (lds_int*)s_stack + K * RENDER_BLOCK;
+    int deep[K > 0 ? STACK_DEPTH - K : 1];
     lds_float* wray = INST ? (lds_float*)(s_wray + threadIdx.x) : nullptr;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t mine = 0xFFFFFFFFu;  // index of the ray this lane is walking (or has walked and not yet written)
@@ -503,7 +521,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 3 : 4) void k_trace_stream(Sce
                 const rrt_ray r = rays[mine];
                 o = v3(r.origin[0], r.origin[1], r.origin[2]);
                 d = v3(r.direction[0], r.direction[1], r.direction[2]);
-                trav_begin<INST>(S, o, d, tmax, stack, RENDER_BLOCK, T);
+                trav_begin<MODE>(S, o, d, tmax, stack, RENDER_BLOCK, T);
             }
             blk += take;
             continue;
@@ -511,8 +529,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, INST ? 3 : 4) void k_trace_stream(Sce
         const uint32_t n_walk = 64u - n_idle;
         const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0 || (INST && trav_due(T.cur))));
         const uint32_t share = (n_walk * node_share_64ths) >> 6;
-        if (n_desc >= share) trav_nodes<INST, COUNT, 0, 3>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share, nullptr, nullptr, wray);
-        if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<INST, COUNT, 0, true>(S, o, d, tmin, RENDER_BLOCK, T, cnt, nullptr, nullptr, wray);
+        if (n_desc >= share) trav_nodes<MODE, COUNT, K, 3>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+        if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, tmin, RENDER_BLOCK, T, cnt, lim, deep, wray);
     }
     if (COUNT) {
         const unsigned long long nn = wave_sum((unsigned long long)cnt.nodes);
@@ -613,14 +631,14 @@ uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t s
     return (uint32_t)n;
 }
 
-template <bool INST, bool COUNT, bool PIPELINED>
+template <int MODE, bool COUNT, bool PIPELINED>
 static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, float* out, unsigned long long* d_counters,
                                         unsigned int* d_heads, int cu_count, hipStream_t stream) {
     // persistent grid: as many workgroups as the chip holds at once (never more than there are work items)
     static int blocks_per_cu = 0;  // per template instantiation
     if (blocks_per_cu == 0) {
         int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<INST, COUNT, PIPELINED>, RENDER_BLOCK, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<MODE, COUNT, PIPELINED>, RENDER_BLOCK, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = n > 0 ? n : 1;
         // experiment knob: fewer resident workgroups per CU (occupancy sensitivity)
@@ -633,7 +651,7 @@ static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, 
     const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;
     if (blocks > needed) blocks = needed;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((k_render<INST, COUNT, PIPELINED>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
+    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
     return hipGetLastError();
 }
 
@@ -655,20 +673,24 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     G.leave_walk = tuning.leave_walk;
     G.leave_ready = tuning.leave_ready;
     float* out = n_chunks > 1u ? d_partial : d_accum;
-    const bool inst = S.has_instances != 0u;
+    const int mode = S.unroll_shift != 0u ? MODE_UNROLLED : (S.has_instances != 0u ? MODE_TWO_LEVEL : MODE_FLAT);
     hipError_t e;
     // the pipelined form packs a lane's pixel coordinates into 16 bits each
     const bool pipelined = tuning.overlap_items != 0u && width < 65536u && height < 65536u;
-    const unsigned variant = (inst ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
+    const unsigned variant = ((unsigned)mode << 2) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
     switch (variant) {
-        case 7u: e = launch_render_variant<true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 6u: e = launch_render_variant<true, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 5u: e = launch_render_variant<true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 4u: e = launch_render_variant<true, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 3u: e = launch_render_variant<false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 2u: e = launch_render_variant<false, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 1u: e = launch_render_variant<false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        default: e = launch_render_variant<false, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 11u: e = launch_render_variant<MODE_UNROLLED, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 10u: e = launch_render_variant<MODE_UNROLLED, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 9u: e = launch_render_variant<MODE_UNROLLED, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 8u: e = launch_render_variant<MODE_UNROLLED, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 7u: e = launch_render_variant<MODE_TWO_LEVEL, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 6u: e = launch_render_variant<MODE_TWO_LEVEL, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 5u: e = launch_render_variant<MODE_TWO_LEVEL, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 4u: e = launch_render_variant<MODE_TWO_LEVEL, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 3u: e = launch_render_variant<MODE_FLAT, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 2u: e = launch_render_variant<MODE_FLAT, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 1u: e = launch_render_variant<MODE_FLAT, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        default: e = launch_render_variant<MODE_FLAT, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
     }
     if (e != hipSuccess || n_chunks <= 1u) return e;
     const uint32_t n_floats = width * height * 3u;
@@ -676,21 +698,21 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     return hipGetLastError();
 }
 
-template <bool INST, bool COUNT>
+template <int MODE, bool COUNT>
 static hipError_t launch_trace_variant(const SceneDev& S, const rrt_ray* d_rays, uint32_t n, float tmin, float tmax,
                                        rrt_hit* d_out, unsigned long long* d_counters, unsigned int* d_head, int cu_count,
                                        const RenderTuning& tuning, hipStream_t stream) {
     static int blocks_per_cu = 0;  // per template instantiation
     if (blocks_per_cu == 0) {
         int k = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_trace_stream<INST, COUNT>, RENDER_BLOCK, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_trace_stream<MODE, COUNT>, RENDER_BLOCK, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = k > 0 ? k : 1;
     }
     unsigned long long blocks = (unsigned long long)blocks_per_cu * (unsigned)cu_count;
     const unsigned long long needed = ((unsigned long long)n + RENDER_BLOCK - 1ull) / RENDER_BLOCK;
     if (blocks > needed) blocks = needed;
-    hipLaunchKernelGGL((k_trace_stream<INST, COUNT>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, d_rays, n, tmin,
+    hipLaunchKernelGGL((k_trace_stream<MODE, COUNT>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, d_rays, n, tmin,
                        tmax, d_out, d_head, tuning.refill_min, tuning.node_share_64ths, d_counters);
     return hipGetLastError();
 }
@@ -699,20 +721,26 @@ hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, 
                             unsigned long long* d_counters, unsigned int* d_head, int cu_count, bool count_visits,
                             const RenderTuning& tuning, hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    const int mode = S.unroll_shift != 0u ? MODE_UNROLLED : (S.has_instances != 0u ? MODE_TWO_LEVEL : MODE_FLAT);
     if (getenv("RRT_INTERSECT_STATIC")) {  // experiment knob: the plain one-lane-per-ray kernel
         dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
-        if (S.has_instances)
-            hipLaunchKernelGGL((k_intersect<true>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
+        if (mode == MODE_UNROLLED)
+            hipLaunchKernelGGL((k_intersect<MODE_UNROLLED>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
+        else if (mode == MODE_TWO_LEVEL)
+            hipLaunchKernelGGL((k_intersect<MODE_TWO_LEVEL>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
         else
-            hipLaunchKernelGGL((k_intersect<false>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
+            hipLaunchKernelGGL((k_intersect<MODE_FLAT>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);
         return hipGetLastError();
     }
-    const bool inst = S.has_instances != 0u;
     const uint32_t m = (uint32_t)n;
-    if (inst && count_visits) return launch_trace_variant<true, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
-    if (inst) return launch_trace_variant<true, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
-    if (count_visits) return launch_trace_variant<false, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
-    return launch_trace_variant<false, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+    switch (mode * 2 + (count_visits ? 1 : 0)) {
+        case 5: return launch_trace_variant<MODE_UNROLLED, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+        case 4: return launch_trace_variant<MODE_UNROLLED, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+        case 3: return launch_trace_variant<MODE_TWO_LEVEL, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+        case 2: return launch_trace_variant<MODE_TWO_LEVEL, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+        case 1: return launch_trace_variant<MODE_FLAT, true>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+        default: return launch_trace_variant<MODE_FLAT, false>(S, d_rays, m, tmin, tmax, d_out, d_counters, d_head, cu_count, tuning, stream);
+    }
 }
 
 hipError_t launch_add(float* d_dst, const float* d_src, size_t n, hipStream_t stream) {

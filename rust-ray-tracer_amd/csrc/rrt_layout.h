@@ -143,12 +143,14 @@ struct SceneDev {
     const TriRec* tris;
     const SphereRec* spheres;
     const RectRec* rects;
-    const InstRec* insts;
+    const InstRec* insts;     // insts[-1] is an identity record (what a triangle outside every instance reads in an unrolled scene)
     const MatRec* mats;
     const LightRec* lights;
     uint32_t light_count;
     int32_t root;       // root node of the top-level BVH
-    uint32_t has_instances;
+    uint32_t has_instances;   // instance leaves in the top-level BVH (two-level walk)
+    uint32_t unroll_shift;    // != 0: instances unrolled into one world-space tree; a triangle leaf's 25-bit field is
+                              // (instance slot << unroll_shift) | first record, slot 0 = not instanced
     uint32_t light_zone;  // 2^32 mod light_count (rejection zone of the uniform light pick)
     CameraRec cam;
     float background[3];

@@ -2,6 +2,7 @@
 #include "scene_build.h"
 
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <atomic>
@@ -86,7 +87,18 @@ struct Expander {
         uint32_t depth;
         float mn[3], mx[3];
         Grid grid;
+        // for unrolling (instances written out as world-space trees over the mesh's leaves): the triangle leaves of
+        // the host-built tree (reference words: count and first record), its node count and depth budget, the mesh's
+        // range of the leaf-ordered records, and whether the mesh holds triangles only
+        std::vector<uint32_t> leaves;
+        uint32_t node_count = 0, budget = 0;
+        uint32_t tri_base = 0, tri_count = 0;
+        bool tri_only = false, host_built = false;
     };
+    // Unrolled scenes: world box of each instance's triangles (indexed like d->instances), computed before the world
+    // list is expanded; empty when the scene is not unrolled.
+    std::vector<std::array<float, 6>> inst_world_box;
+    std::vector<uint32_t> inst_of_record;  // per InstRec pushed: the index of its rrt_instance
     bool expand(const rrt_object* objs, uint32_t n_objs, uint32_t& id, std::vector<BuildPrim>& prims,
                 const std::vector<MeshInfo>* meshes) {
         {   // one growth of the big arrays instead of one per run (a scene may list its triangles in many runs)
@@ -202,6 +214,9 @@ struct Expander {
                     id += mi.prim_count;
                     BuildPrim p;
                     for (int a = 0; a < 3; ++a) { p.bmin[a] = FLT_MAX; p.bmax[a] = -FLT_MAX; }
+                    if (!inst_world_box.empty()) {  // unrolled: the padded world box of the instance's own triangles
+                        for (int a = 0; a < 3; ++a) { p.bmin[a] = inst_world_box[ob.first][a]; p.bmax[a] = inst_world_box[ob.first][3 + a]; }
+                    } else
                     for (int c = 0; c < 8; ++c) {  // world box of the rotated + translated mesh box
                         const float x = (c & 1) ? mi.mx[0] : mi.mn[0];
                         const float y = (c & 2) ? mi.mx[1] : mi.mn[1];
@@ -212,8 +227,11 @@ struct Expander {
                     }
                     p.kind = KIND_INST;
                     p.index = (uint32_t)hs->insts.size();
-                    widen(p);
-                    widen(p);
+                    if (inst_world_box.empty()) {
+                        widen(p);
+                        widen(p);
+                    }
+                    inst_of_record.push_back(ob.first);
                     hs->insts.push_back(rec);
                     prims.push_back(p);
                     break;
@@ -281,6 +299,87 @@ static Grid quantize_nodes(HostScene& hs, const std::vector<BvhNode>& built, con
 
 }  // namespace
 
+// ---- unrolled instances -----------------------------------------------------------------------------------------
+// An instance (Translate(RotateY(mesh)), reference src/geometry/transform.rs) can be written out as a tree of its own
+// whose boxes are in world space, hung into the top-level tree in place of the instance leaf.  Traversal then never
+// changes space: only the triangle test does, on the mesh's object-space records, with the ray moved into the
+// instance's space exactly as the reference moves it.  The copy keeps the mesh tree's LEAVES (runs of the mesh's
+// leaf-ordered records, which all instances of the mesh share); the levels above them are built anew per instance by the
+// SAH builder over the leaves' world boxes: the splits the mesh's own tree chose are good along the mesh's axes and
+// poor along the world's once the mesh is rotated (kept as they are, with refitted boxes, the copies cost 10 % more
+// node visits and 18 % more triangle tests than the two-level walk).
+
+// Padded world box of the triangle the reference's test sees for record `r` (v0, v0 + e1, v0 + e2: triangle.rs:17-18
+// caches the edges) under the instance's point map x' = cos x + sin z, z' = -sin x + cos z, then + offset
+// (transform.rs:27,113-124).  The pad is the one every triangle box carries: the reference's 1e-4 (triangle.rs:82-94)
+// plus the builder's 2^-17 of the scene's extent.  What the latter has to cover here besides the slab test's own error
+// (1/16 of it): the ray is moved into object space in f32, so the point the test accepts there, moved back to world
+// space, lies off the world ray by the rounding of that move, at most about 8e-7 of the extent (a tenth of the pad).
+static void world_tri_box(const TriRec& r, const rrt_instance& in, float pad, float* mn, float* mx) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int k = 0; k < 3; ++k) {
+        double p[3];
+        for (int a = 0; a < 3; ++a) p[a] = (double)r.v0[a] + (k == 1 ? (double)r.e1[a] : (k == 2 ? (double)r.e2[a] : 0.0));
+        const double w[3] = {(double)in.cos_theta * p[0] + (double)in.sin_theta * p[2] + (double)in.offset[0], p[1] + (double)in.offset[1],
+                             -(double)in.sin_theta * p[0] + (double)in.cos_theta * p[2] + (double)in.offset[2]};
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], w[a]); hi[a] = std::max(hi[a], w[a]); }
+    }
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = std::nextafterf((float)lo[a], -INFINITY) - 0.0001f - pad;
+        mx[a] = std::nextafterf((float)hi[a], INFINITY) + 0.0001f + pad;
+    }
+}
+
+// The tree of one instance: `leaves` are the mesh's triangle leaves (reference words: count and first record);
+// `prims` receives one primitive per leaf with the world box of its triangles (also the instance's world box, in
+// mn/mx).  `rec(i)`: triangle record i of the scene's leaf-ordered record array.
+template <typename RecFn>
+static void instance_leaf_prims(const std::vector<uint32_t>& leaves, const rrt_instance& in, float pad, RecFn rec,
+                                std::vector<BuildPrim>& prims, float* mn, float* mx) {
+    prims.resize(leaves.size());
+    for (int a = 0; a < 3; ++a) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; }
+    for (size_t k = 0; k < leaves.size(); ++k) {
+        const uint32_t first = leaves[k] & REF_OFFSET_MASK, cnt = ((leaves[k] >> 25) & 7u) + 1u;
+        BuildPrim& p = prims[k];
+        for (int a = 0; a < 3; ++a) { p.bmin[a] = FLT_MAX; p.bmax[a] = -FLT_MAX; }
+        for (uint32_t j = 0; j < cnt; ++j) {
+            float tmn[3], tmx[3];
+            world_tri_box(rec(first + j), in, pad, tmn, tmx);
+            for (int a = 0; a < 3; ++a) { p.bmin[a] = std::min(p.bmin[a], tmn[a]); p.bmax[a] = std::max(p.bmax[a], tmx[a]); }
+        }
+        p.kind = KIND_SUBTREE;
+        p.index = (uint32_t)k;
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p.bmin[a]); mx[a] = std::max(mx[a], p.bmax[a]); }
+    }
+}
+
+// Builds the instance's tree over `prims` (see above) and writes it, on grid g, to out[0 .. nodes): node k becomes
+// node copy_base + k, the root first.  Triangle leaves carry (slot << shift) | first record.  Returns the tree's node
+// levels, or 0 if it came out with another node count than `nodes` (= leaves - 1, or 1 for a single leaf).
+static uint32_t build_instance_tree(std::vector<BuildPrim>& prims, const std::vector<uint32_t>& leaves, uint32_t slot, uint32_t shift,
+                                    uint32_t copy_base, uint32_t nodes, uint32_t budget, const Grid& g, QNode* out) {
+    std::vector<BvhNode> built;
+    std::vector<uint32_t> no_tris;
+    const BuildResult br = build_bvh(prims, built, no_tris, 0u, budget, 1u, (int64_t)copy_base);
+    if (built.size() != (size_t)nodes || br.root != (int32_t)copy_base) return 0u;
+    auto final_ref = [&](int32_t ref) -> int32_t {
+        if (ref >= 0) return device_ref(ref);
+        const uint32_t u = (uint32_t)ref;
+        if (((u >> 28) & 7u) != KIND_SUBTREE) return ref;  // an empty child slot
+        const uint32_t leaf = leaves[u & REF_OFFSET_MASK];
+        return (int32_t)((leaf & ~REF_OFFSET_MASK) | (slot << shift) | (leaf & REF_OFFSET_MASK));
+    };
+    for (uint32_t k = 0; k < nodes; ++k) {
+        const BvhNode& nd = built[k];
+        QNode& q = out[k];
+        q.left = final_ref(nd.left);
+        q.right = final_ref(nd.right);
+        quantize_box(g, nd.lmin, nd.lmax, q.lbox);
+        quantize_box(g, nd.rmin, nd.rmax, q.rbox);
+    }
+    return br.depth;
+}
+
 // Reserves nodes and triangle slots for a BVH the GPU will build; returns its root box in mn/mx.
 static void defer_build(HostScene& hs, std::vector<BuildPrim>& prims, std::vector<uint32_t>& tri_order, uint32_t budget,
                         int mesh, float* mn, float* mx, int32_t& root, Grid& grid, unsigned threads) {
@@ -342,7 +441,7 @@ struct PhaseTrace {
 };
 
 rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string& err, unsigned threads,
-                            uint32_t device_build_min) {
+                            uint32_t device_build_min, bool unroll) {
     PhaseTrace trace;
     hs = HostScene();
     if (!d) { err = "scene is NULL"; return RRT_ERR_INVALID; }
@@ -443,9 +542,18 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
             continue;
         }
         std::vector<BvhNode> built;
+        meshes[mi].tri_base = (uint32_t)tri_order.size();
+        meshes[mi].tri_only = std::all_of(prims.begin(), prims.end(), [](const BuildPrim& p) { return p.kind == KIND_TRI; });
         BuildResult br = build_bvh(prims, built, tri_order, (uint32_t)tri_order.size(), budget, threads, (int64_t)hs.qnodes.size());
+        meshes[mi].tri_count = (uint32_t)tri_order.size() - meshes[mi].tri_base;
         meshes[mi].grid = quantize_nodes(hs, built, br.root_min, br.root_max, threads);
         if (br.depth > budget) { err = "mesh too large for the traversal stack of an instanced scene"; return RRT_ERR_INVALID; }
+        meshes[mi].host_built = true;
+        meshes[mi].node_count = (uint32_t)built.size();
+        meshes[mi].budget = budget;
+        for (const BvhNode& nd : built)
+            for (int32_t ref : {nd.left, nd.right})
+                if (ref < 0 && (((uint32_t)ref >> 28) & 7u) == KIND_TRI) meshes[mi].leaves.push_back((uint32_t)ref);
         meshes[mi].root = br.root;
         meshes[mi].prim_count = id;
         meshes[mi].depth = br.depth;
@@ -455,6 +563,54 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     }
 
     trace.mark("meshes");
+    // Unroll the instances into one world-space tree?  Only when every instanced mesh was built here and holds
+    // triangles only, the copies stay within a node budget (RRT_UNROLL_MAX_NODES, default 2^24 = 512 MB of nodes), and a
+    // triangle leaf's 25-bit field has room for (instance slot, first record).
+    uint32_t unroll_shift = 0;
+    if (unroll && d->instance_count > 0u) {
+        bool ok = true;
+        uint64_t copy_nodes = 0, world_tris = 0;
+        for (uint32_t i = 0; i < d->world_count && ok; ++i) {
+            const rrt_object& ob = d->world[i];
+            if (ob.type == RRT_OBJ_TRIANGLES) world_tris += ob.count;
+            if (ob.type != RRT_OBJ_INSTANCE) continue;
+            if (ob.count != 1u || ob.first >= d->instance_count || d->instances[ob.first].mesh >= d->mesh_count) { ok = false; break; }  // reported by expand()
+            const Expander::MeshInfo& mi = meshes[d->instances[ob.first].mesh];
+            ok = mi.host_built && mi.tri_only && mi.tri_count > 0u;
+            copy_nodes += mi.node_count;
+        }
+        uint64_t max_nodes = 1ull << 24;
+        if (const char* e = std::getenv("RRT_UNROLL_MAX_NODES")) max_nodes = (uint64_t)std::max(0ll, std::atoll(e));
+        const uint64_t records = (uint64_t)tri_order.size() + world_tris + MAX_LEAF_TRIS;
+        uint32_t shift = 1;
+        while ((1ull << shift) < records) ++shift;
+        if (ok && copy_nodes > 0u && copy_nodes <= max_nodes && hs.qnodes.size() + copy_nodes + 2u * d->world_count + 64u < (uint64_t)REF_OFFSET_MASK &&
+            shift < 25u && (uint64_t)d->instance_count < (1ull << (25u - shift)))
+            unroll_shift = shift;
+    }
+    // per instance: one primitive per leaf of its mesh, with the world box of the leaf's triangles (kept for the build
+    // of the instance's tree, which has to wait for the top level's grid)
+    std::vector<std::vector<BuildPrim>> inst_prims;
+    auto rec_of = [&](uint32_t i) -> const TriRec& { return ex.tri_src[tri_order[i]]; };
+    if (unroll_shift) {
+        ex.inst_world_box.resize(d->instance_count);
+        inst_prims.resize(d->instance_count);
+        std::vector<std::thread> pool;
+        std::atomic<uint32_t> next{0};
+        auto work = [&]() {
+            for (uint32_t i; (i = next.fetch_add(1)) < d->instance_count;) {
+                const rrt_instance& in = d->instances[i];
+                std::array<float, 6>& b = ex.inst_world_box[i];
+                b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (in.mesh >= d->mesh_count || meshes[in.mesh].leaves.empty()) continue;
+                instance_leaf_prims(meshes[in.mesh].leaves, in, ex.pad, rec_of, inst_prims[i], b.data(), b.data() + 3);
+            }
+        };
+        for (unsigned t = 1; t < std::min<unsigned>(threads, d->instance_count); ++t) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+        trace.mark("instance leaf boxes");
+    }
     std::vector<BuildPrim> prims;
     uint32_t id = 0;
     if (!ex.expand(d->world, d->world_count, id, prims, &meshes)) return RRT_ERR_INVALID;
@@ -477,9 +633,52 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         hs.root = br.root;
         hs.top_depth = br.depth;
         hs.depth = br.depth + (hs.insts.empty() ? 0u : deepest_mesh);
+        if (unroll_shift && !hs.insts.empty()) {
+            // one world-space tree per instance, on the top level's grid, behind the nodes there are; then every
+            // instance leaf of the top level becomes a reference to its instance's root
+            const size_t top_first = hs.qnodes.size() - built.size(), top_end = hs.qnodes.size();
+            std::vector<uint32_t> copy_base(hs.insts.size());
+            size_t total = top_end;
+            for (size_t r = 0; r < hs.insts.size(); ++r) {
+                copy_base[r] = (uint32_t)total;
+                total += meshes[d->instances[ex.inst_of_record[r]].mesh].node_count;
+            }
+            hs.qnodes.resize(total);
+            std::vector<std::thread> pool;
+            std::atomic<uint32_t> next{0}, deepest{0};
+            std::atomic<bool> failed{false};
+            auto work = [&]() {
+                for (uint32_t r; (r = next.fetch_add(1)) < hs.insts.size();) {
+                    const uint32_t i = ex.inst_of_record[r];
+                    const Expander::MeshInfo& mi = meshes[d->instances[i].mesh];
+                    const uint32_t depth = build_instance_tree(inst_prims[i], mi.leaves, r + 1u, unroll_shift, copy_base[r], mi.node_count,
+                                                               mi.budget, hs.grid, hs.qnodes.data() + copy_base[r]);
+                    if (depth == 0u || depth > mi.budget) failed.store(true);
+                    uint32_t seen = deepest.load();
+                    while (depth > seen && !deepest.compare_exchange_weak(seen, depth)) {}
+                    std::vector<BuildPrim>().swap(inst_prims[i]);
+                }
+            };
+            for (unsigned t = 1; t < std::min<unsigned>(threads, (unsigned)hs.insts.size()); ++t) pool.emplace_back(work);
+            work();
+            for (std::thread& t : pool) t.join();
+            if (failed.load()) { err = "instance tree does not fit the traversal stack"; return RRT_ERR_INVALID; }
+            for (size_t k = top_first; k < top_end; ++k) {
+                int32_t* refs[2] = {&hs.qnodes[k].left, &hs.qnodes[k].right};
+                for (int32_t* ref : refs) {
+                    const uint32_t u = (uint32_t)*ref;
+                    if (*ref < 0 && ((u >> 28) & 7u) == KIND_INST) *ref = device_ref((int32_t)copy_base[u & REF_OFFSET_MASK]);
+                }
+            }
+            hs.unroll_shift = unroll_shift;
+            hs.unrolled_instances = (uint32_t)hs.insts.size();
+            hs.deepest_mesh = std::max(hs.deepest_mesh, deepest.load());
+            hs.depth = br.depth + hs.deepest_mesh;
+            trace.mark("instances unrolled");
+        }
     }
     trace.mark("top-level BVH (or deferral)");
-    hs.has_instances = !hs.insts.empty();
+    hs.has_instances = !hs.insts.empty() && hs.unroll_shift == 0u;
     if (tri_order.size() > REF_OFFSET_MASK) { err = "too many triangles"; return RRT_ERR_INVALID; }
     if (hs.qnodes.size() > (size_t)REF_OFFSET_MASK) { err = "too many BVH nodes"; return RRT_ERR_INVALID; }  // device_ref: byte offsets below 2^30
 

@@ -38,15 +38,19 @@ struct HostScene {
     uint32_t top_depth = 0;        // node levels of the top-level BVH (0 while its build is deferred)
     uint32_t deepest_mesh = 0;     // node levels of the deepest host-built mesh BVH
     std::vector<DeferredBuild> deferred;
-    bool has_instances = false;
+    bool has_instances = false;    // instance leaves in the top-level BVH (two-level walk)
+    uint32_t unroll_shift = 0;     // != 0: instances unrolled into the top-level tree (SceneDev::unroll_shift)
+    uint32_t unrolled_instances = 0;
     CameraRec cam{};
     float background[3] = {0.f, 0.f, 0.f};
 };
 
 // Returns RRT_OK or RRT_ERR_INVALID with a message.  `threads` host threads are used for the BVH build.
 // device_build_min > 0: BVHs over at least that many primitives are not built here but listed in out.deferred.
+// unroll: instances may be written out as world-space copies of their mesh's tree inside the top-level BVH (done when
+// every instanced mesh is host-built and triangle-only and the copies fit the node budget); false: always two-level.
 rrt_status build_host_scene(const rrt_scene_desc* desc, HostScene& out, std::string& err, unsigned threads,
-                            uint32_t device_build_min = 0);
+                            uint32_t device_build_min = 0, bool unroll = true);
 
 // Grid of 65536 planes per axis over the box [mn, mx] of a BVH's root.
 Grid make_grid(const float* mn, const float* mx);

@@ -75,6 +75,41 @@ def scene_instanced(rrt):
     return s
 
 
+def scene_instanced_tris(rrt):
+    """Triangle-only meshes instanced as Translate(RotateY(mesh)): the kind of scene the library unrolls into one
+    world-space tree (two meshes, 12 instances, top-level triangles, a light)."""
+    from rust_ray_tracer_amd import scenes
+
+    s = rrt.Scene()
+    grey = s.add_material(rrt.Lambertian(0.7, 0.7, 0.7))
+    metal = s.add_material(rrt.Metal((0.8, 0.8, 0.9), 0.1))
+    glass = s.add_material(rrt.Dielectric(1.5))
+    light = s.add_material(rrt.DiffuseLight(300.0, 300.0, 300.0))
+    m = s.new_mesh()
+    tris = scenes.blob_mesh(16, 20, 0.8, 0.4, seed=4)
+    s.add_triangles(tris[: len(tris) // 2], grey, mesh=m)
+    s.add_triangles(tris[len(tris) // 2:], metal, mesh=m)
+    blob = s.finish_mesh(m)
+    m = s.new_mesh()
+    s.add_triangles(scenes.blob_mesh(6, 7, 0.45, 0.2, seed=9), glass, mesh=m)
+    small = s.finish_mesh(m)
+    g = np.array([[[-9, -1.2, -9], [-9, -1.2, 9], [9, -1.2, -9]], [[9, -1.2, -9], [-9, -1.2, 9], [9, -1.2, 9]]], np.float32)
+    s.add_triangles(g, grey)
+    k = 0
+    for i in range(3):
+        for j in range(3):
+            s.add_instance(blob, angle_deg=41.0 * k - 120.0, offset=((i - 1) * 2.5 + 0.1 * k, 0.0, (j - 1) * 2.5 - 0.05 * k))
+            k += 1
+    for k in range(3):
+        s.add_instance(small, angle_deg=100.0 * k, offset=(-2.0 + 2.0 * k, 1.6, 0.4 * k))
+    lp = (0.0, 6.0, 1.0)
+    s.add_sphere(lp, 0.5, light)
+    s.add_sphere_light(lp, 0.5)
+    s.camera = rrt.Camera(16.0 / 9.0, 42.0, scenes.look_at_c2w((0.5, 5.0, 9.0), (0.0, 0.0, 0.0)))
+    s.background = (0.051, 0.051, 0.051)
+    return s
+
+
 def scene_cornell(rrt):
     from rust_ray_tracer_amd import scenes
 
@@ -93,6 +128,7 @@ SCENES = {
     "suzanne": scene_suzanne,
     "mixed": scene_mixed,
     "instanced": scene_instanced,
+    "instanced_tris": scene_instanced_tris,
     "cornell": scene_cornell,
     "synthetic": scene_synthetic_small,
 }

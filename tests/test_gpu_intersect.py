@@ -9,7 +9,7 @@ import helpers
 
 pytestmark = pytest.mark.gpu
 
-SCENE_NAMES = ["default", "suzanne", "mixed", "instanced", "cornell", "synthetic"]
+SCENE_NAMES = ["default", "suzanne", "mixed", "instanced", "instanced_tris", "cornell", "synthetic"]
 
 
 @pytest.fixture(scope="module")
@@ -47,6 +47,26 @@ def test_golden_vectors(rrt, renderer_cache, golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"rays_{name}.npz"))
     for kind in ("primary", "bounce", "adversarial"):
         helpers.assert_hits_match(r.intersect(g[f"{kind}_rays"]), g[f"{kind}_hits"])
+
+
+def test_unrolled_and_two_level_instances_give_the_same_hits(rrt, oracle, renderer_cache):
+    """Triangle-only instanced meshes are written out as world-space copies of their tree inside the top-level BVH by
+    default; RRT_CFG_NO_UNROLL keeps the two-level walk of the reference (src/geometry/transform.rs:22-31,99-130).  Both
+    run the same primitive tests on the same operands: records identical bit for bit, and equal to the oracle's."""
+    r, scene = get(rrt, renderer_cache, "instanced_tris")
+    assert r.info().unrolled_instances == 12
+    two = rrt.Renderer(unroll_instances=False)
+    info = two.upload(scene)
+    assert info.unrolled_instances == 0 and info.node_count < r.info().node_count
+    o = oracle.OracleScene(scene)
+    for kind, rays in helpers.ray_suite(scene, o, n=4096, seed=5).items():
+        a, b = r.intersect(rays), two.intersect(rays)
+        assert np.array_equal(a, b), kind
+        helpers.assert_hits_match(a, o.intersect(rays))
+    two.close()
+    # a mesh that holds anything but triangles keeps the two-level form
+    r2, _ = get(rrt, renderer_cache, "instanced")
+    assert r2.info().unrolled_instances == 0
 
 
 def test_t_range_arguments(rrt, oracle, renderer_cache):

@@ -30,7 +30,8 @@ def rel_l1(a, b):
 
 
 @pytest.mark.parametrize("name,w,h,spp", [("default", 142, 80, 8), ("suzanne", 160, 90, 4), ("mixed", 96, 54, 8),
-                                          ("instanced", 96, 54, 4), ("cornell", 64, 64, 8), ("synthetic", 96, 54, 4)])
+                                          ("instanced", 96, 54, 4), ("instanced_tris", 96, 54, 4), ("cornell", 64, 64, 8),
+                                          ("synthetic", 96, 54, 4)])
 def test_same_seed_image_matches_the_oracle(rrt, oracle, name, w, h, spp):
     scene = helpers.SCENES[name](rrt)
     r = rrt.Renderer(device=0, seed=11)
@@ -151,7 +152,7 @@ def test_sample_counts_that_do_not_fill_their_chunks(rrt, monkeypatch, spp, chun
     r.close()
 
 
-@pytest.mark.parametrize("name", ["synthetic", "instanced"])
+@pytest.mark.parametrize("name", ["synthetic", "instanced", "instanced_tris"])
 def test_image_does_not_depend_on_wave_scheduling(rrt, monkeypatch, name):
     """How a wavefront orders its passes (share of descending lanes that keeps a node pass going, how many stragglers
     a trip leaves behind, how many lanes must wait before it does) changes the timing only: every pixel follows the same
@@ -175,6 +176,19 @@ def test_image_does_not_depend_on_wave_scheduling(rrt, monkeypatch, name):
         for k in knobs:
             monkeypatch.delenv(k)
     r.close()
+
+
+def test_unrolled_and_two_level_instances_render_the_same_image(rrt):
+    """The unrolled form of an instanced scene (default for triangle-only meshes) and the two-level form follow the same
+    paths: identical ray counts and images, bit for bit."""
+    scene = helpers.scene_instanced_tris(rrt)
+    a, b = rrt.Renderer(seed=7), rrt.Renderer(seed=7, unroll_instances=False)
+    assert a.upload(scene).unrolled_instances == 12 and b.upload(scene).unrolled_instances == 0
+    ia, sa = a.render(160, 90, 8)
+    ib, sb = b.render(160, 90, 8)
+    assert sa.rays == sb.rays and np.array_equal(ia, ib)
+    a.close()
+    b.close()
 
 
 def test_odd_sizes_and_single_sample(rrt, oracle, monkeypatch):

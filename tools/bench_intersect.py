@@ -15,6 +15,8 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 import rrt_pkg  # noqa: E402
 
+ITERS = int(os.environ.get("RRT_INTERSECT_ITERS", "5"))
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -48,11 +50,11 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for _ in range(5):
+        for _ in range(ITERS):
             r.intersect_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), stream=stream.cuda_stream)
         e1.record(stream)
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        ms = e0.elapsed_time(e1) / ITERS
         hits = d_hits.cpu().numpy().view(rrt.HIT_DTYPE)
         rc.intersect_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), stream=stream.cuda_stream)
         st = rc.render_stats()

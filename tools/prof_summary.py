@@ -22,7 +22,8 @@ def main():
             meta = {}
             for r in rows:
                 name = r["Kernel_Name"]
-                if "k_render" not in name or "true>" in name.split("k_render")[1][:16].replace(" ", "").split(",")[-1]:
+                want = os.environ.get("RRT_PROF_KERNEL", "k_render")  # kernel the summary is about
+                if want not in name or (want == "k_render" and "true>" in name.split("k_render")[1][:16].replace(" ", "").split(",")[-1]):
                     continue  # only the plain (non-counting) render kernel
                 key = (name[:48], r["Dispatch_Id"])
                 agg.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
