@@ -34,6 +34,10 @@ GPU_GHZ = 2.4
 SIMDS = 1024
 VALU_CYCLES_PER_WAVE_INST = 2.0
 ISSUE_PEAK_GINST = SIMDS * GPU_GHZ / VALU_CYCLES_PER_WAVE_INST  # 1228.8 G wave-instructions per second
+# Vector L1 address path: a CU's one address unit takes 16 cycles per wavefront load instruction of 8 to 16 bytes per
+# lane, however many lanes are switched on (measured: tools/l1_rate.hip), and one more per 128-byte line beyond 16.
+CUS = 256
+L1_CYCLES_PER_WAVE_LOAD = 16.0
 
 
 def parse_args():
@@ -276,6 +280,11 @@ def main():
                 "lane_util_hw": (pmc["sq_thread_cycles_valu"] / (64.0 * pmc["sq_active_inst_valu"])) if pmc.get("sq_active_inst_valu") else None,
                 "insts_per_ray": insts, "valu_per_ray": pmc["sq_insts_valu"] * per_ray, "salu_per_ray": pmc.get("sq_insts_salu", 0.0) * per_ray,
                 "simd_cycles_per_inst": k_s * GPU_GHZ * 1e9 * SIMDS / (insts * rays_per_step),
+                # the other resource the kernel nearly fills: the address unit of each CU's vector L1.  floor: wavefront
+                # load instructions x 16 cycles / (CUs x kernel cycles); busy: the unit's own busy counter (TA_BUSY)
+                "l1_loads_per_ray": pmc.get("sq_insts_vmem_rd", 0.0) * per_ray,
+                "l1_addr_floor_frac": pmc.get("sq_insts_vmem_rd", 0.0) * per_ray * rays_per_step * L1_CYCLES_PER_WAVE_LOAD / (CUS * k_s * GPU_GHZ * 1e9),
+                "l1_addr_busy_frac": pmc.get("ta_busy_frac"),
                 "waves_per_simd": pmc.get("waves_per_simd"),
                 "pmc_source": f"profiles/pmc_per_launch.json [{args.config}] ({pmc.get('source', 'rocprofv3 --pmc, tools/prof.sh')}), profiled at {pmc.get('spp_per_gpu')} spp, used per ray"})
             if hbm_frac < 0.10:
@@ -286,7 +295,10 @@ def main():
                 roof.update({"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac})
             roof["note"] = ("bound=issue: frac = vector wave-instructions x 2 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz), the share of "
                             "the SIMDs' issue slots the kernel fills; lane_util_hw = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) is the "
-                            "share of lanes that work in an issued vector instruction.  bound=hbm: achieved = HBM bytes (FETCH_SIZE x 2 + "
+                            "share of lanes that work in an issued vector instruction.  l1_addr_floor_frac = wavefront load instructions x "
+                            "16 cycles / (256 CUs x kernel cycles): what the loads alone take of each CU's one L1 address unit (16 cycles "
+                            "per load instruction whatever the number of active lanes, tools/l1_rate.hip); l1_addr_busy_frac = TA_BUSY_avr / "
+                            "kernel cycles.  bound=hbm: achieved = HBM bytes (FETCH_SIZE x 2 + "
                             "WRITE_SIZE) / kernel time.  algorithmic_GBps is served by the caches and is not a fraction of any peak.")
         else:
             roof.update({"bound": "issue", "achieved": None, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,

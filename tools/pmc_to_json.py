@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def plain_render(name: str) -> bool:
-    """k_render<INST, COUNT, PIPELINED> with COUNT == false."""
+    """k_render<MODE, COUNT, PIPELINED> with COUNT == false."""
     if "k_render" not in name:
         return False
     args = name.split("k_render")[1].replace(" ", "")
@@ -68,7 +68,8 @@ def main():
               "SQ_WAVES": "sq_waves", "GRBM_GUI_ACTIVE": "grbm_gui_active",
               "TCC_HIT_sum": "tcc_hit", "TCC_MISS_sum": "tcc_miss", "TCP_TOTAL_CACHE_ACCESSES_sum": "tcp_total_cache_accesses",
               "TCP_TCC_READ_REQ_sum": "tcp_tcc_read_req", "TCC_EA0_RDREQ_sum": "tcc_ea0_rdreq", "TCC_EA0_WRREQ_sum": "tcc_ea0_wrreq",
-              "FETCH_SIZE": "fetch_size_kb", "WRITE_SIZE": "write_size_kb"}
+              "FETCH_SIZE": "fetch_size_kb", "WRITE_SIZE": "write_size_kb",
+              "TA_BUSY_avr": "ta_busy_avr", "TA_TA_BUSY_sum": "ta_busy_sum", "TD_TD_BUSY_sum": "td_busy_sum", "TD_TC_STALL_sum": "td_tc_stall_sum"}
     for k, v in counters.items():
         if k in rename:
             row[rename[k]] = v
@@ -76,6 +77,10 @@ def main():
         row["hbm_bytes"] = (2.0 * row["fetch_size_kb"] + row["write_size_kb"]) * 1024.0
     if row.get("sq_active_inst_valu"):
         row["lane_util_hw"] = row["sq_thread_cycles_valu"] / (64.0 * row["sq_active_inst_valu"])
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs: the kernel's cycles are an eighth of it
+    if row.get("grbm_gui_active") and row.get("ta_busy_avr"):
+        row["kernel_cycles"] = row["grbm_gui_active"] / 8.0
+        row["ta_busy_frac"] = row["ta_busy_avr"] / row["kernel_cycles"]
     path = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
     try:
         doc = json.load(open(path))
@@ -84,7 +89,8 @@ def main():
     doc["_comment"] = ("Per-launch PMC figures of k_render from rocprofv3 (tools/prof.sh: one --pmc run per counter group), folded by "
                        "tools/pmc_to_json.py.  FETCH_SIZE / WRITE_SIZE in KB; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 counts "
                        "128-byte read requests as 64 bytes: the factor 2 is an upper estimate).  lane_util_hw = SQ_THREAD_CYCLES_VALU / "
-                       "(64 * SQ_ACTIVE_INST_VALU).  bench.py uses these figures per ray (divided by rays_per_launch).")
+                       "(64 * SQ_ACTIVE_INST_VALU).  ta_busy_frac = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8): the share of the kernel's cycles the address "
+                       "unit of a CU's vector L1 is busy, averaged over the CUs.  bench.py uses these figures per ray (divided by rays_per_launch).")
     doc[str(config)] = row
     json.dump(doc, open(path, "w"), indent=1)
     print(json.dumps(row, indent=1))

@@ -19,5 +19,7 @@ pass pmc5 SQ_INSTS_VALU SQ_WAIT_INST_VMEM SQ_INSTS_SMEM SQ_INST_CYCLES_SALU SQ_I
 # HBM-side traffic: FETCH_SIZE takes 3 TCC slots and WRITE_SIZE 2, so one pass each (values in KB)
 pass pmc6 FETCH_SIZE
 pass pmc7 WRITE_SIZE
+# the address / data path of the vector L1 (one TA and one TD per CU): busy cycles, summed over the units and averaged
+pass pmc8 TA_BUSY_avr TA_TA_BUSY_sum TD_TD_BUSY_sum TD_TC_STALL_sum GRBM_GUI_ACTIVE
 python3 tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

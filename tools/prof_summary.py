@@ -23,8 +23,13 @@ def main():
             for r in rows:
                 name = r["Kernel_Name"]
                 want = os.environ.get("RRT_PROF_KERNEL", "k_render")  # kernel the summary is about
-                if want not in name or (want == "k_render" and "true>" in name.split("k_render")[1][:16].replace(" ", "").split(",")[-1]):
-                    continue  # only the plain (non-counting) render kernel
+                if want not in name:
+                    continue
+                if want == "k_render":
+                    # k_render<MODE, COUNT, PIPELINED>: only the plain (non-counting) form, which is the one that is timed
+                    args = name.split("k_render")[1].replace(" ", "").strip("<").split(">")[0].split(",")
+                    if len(args) >= 2 and args[1] not in ("false", "0"):
+                        continue
                 key = (name[:48], r["Dispatch_Id"])
                 agg.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
                 meta[key] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Grid_Size"), r.get("Workgroup_Size"))
