@@ -475,6 +475,10 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
         tuning.leave_walk = 0u;
         tuning.overlap_items = 0u;
         tuning.band_tiles = 0u;
+    } else if (c->info.node_count >= (1u << 21)) {
+        // the walks of multi-million-node scenes have longer tails: more stragglers are left behind per trip
+        // (measured on MI355X, ten million triangles: 12 -> 20 is 1-2 % faster, flat and unrolled alike)
+        tuning.leave_walk = 20u;
     }
     if (const char* e = std::getenv("RRT_LEAVE_WALK")) tuning.leave_walk = (uint32_t)std::max(0, std::min(63, std::atoi(e)));
     if (const char* e = std::getenv("RRT_LEAVE_READY")) tuning.leave_ready = (uint32_t)std::max(1, std::min(64, std::atoi(e)));

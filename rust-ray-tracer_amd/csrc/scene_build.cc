@@ -311,10 +311,11 @@ static Grid quantize_nodes(HostScene& hs, const std::vector<BvhNode>& built, con
 
 // Padded world box of the triangle the reference's test sees for record `r` (v0, v0 + e1, v0 + e2: triangle.rs:17-18
 // caches the edges) under the instance's point map x' = cos x + sin z, z' = -sin x + cos z, then + offset
-// (transform.rs:27,113-124).  The pad is the one every triangle box carries: the reference's 1e-4 (triangle.rs:82-94)
-// plus the builder's 2^-17 of the scene's extent.  What the latter has to cover here besides the slab test's own error
-// (1/16 of it): the ray is moved into object space in f32, so the point the test accepts there, moved back to world
-// space, lies off the world ray by the rounding of that move, at most about 8e-7 of the extent (a tenth of the pad).
+// (transform.rs:27,113-124).  The pad is the builder's 2^-17 of the scene's extent; the reference's own 1e-4
+// (triangle.rs:82-94: it keeps an axis-aligned triangle's box from being flat) is not carried over: these boxes only have
+// to contain what the triangle test accepts.  What the pad has to cover besides the slab test's own error (1/16 of it):
+// the ray is moved into object space in f32, so the point the test accepts there, moved back to world space, lies
+// off the world ray by the rounding of that move, at most about 8e-7 of the extent (a tenth of the pad).
 static void world_tri_box(const TriRec& r, const rrt_instance& in, float pad, float* mn, float* mx) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int k = 0; k < 3; ++k) {
@@ -325,8 +326,8 @@ static void world_tri_box(const TriRec& r, const rrt_instance& in, float pad, fl
         for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], w[a]); hi[a] = std::max(hi[a], w[a]); }
     }
     for (int a = 0; a < 3; ++a) {
-        mn[a] = std::nextafterf((float)lo[a], -INFINITY) - 0.0001f - pad;
-        mx[a] = std::nextafterf((float)hi[a], INFINITY) + 0.0001f + pad;
+        mn[a] = std::nextafterf((float)lo[a], -INFINITY) - pad;
+        mx[a] = std::nextafterf((float)hi[a], INFINITY) + pad;
     }
 }
 
