@@ -173,7 +173,10 @@ def main():
     gpu_index = local_rank % max(torch.cuda.device_count(), 1) if rehearsal else local_rank
     torch.cuda.set_device(gpu_index)
     device = torch.device("cuda", gpu_index)
-    if world > 1:
+    # RRT_BENCH_FORCE_GROUP=1 (under a launcher, one rank): the process group is set up although there is nobody to
+    # talk to, so that the RCCL calls of the multi-GPU path run on a box with one GPU
+    grouped = world > 1 or (os.environ.get("RRT_BENCH_FORCE_GROUP") == "1" and "WORLD_SIZE" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -217,14 +220,14 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
@@ -316,6 +319,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32",
             "data": ("REHEARSAL, ranks share GPUs, not a measurement; " if rehearsal else "") + data,
+            "process_group": (dist.get_backend() if grouped else None),
             "config": {"workload": f"{workload}, {spp_total} spp" + (f" ({spp} per GPU)" if world > 1 else ""),
                        "width": width, "height": height, "spp_per_gpu": spp, "spp_total": spp_total,
                        "max_depth": 4, "prims": info.prim_count, "bvh_nodes": info.node_count, "bvh_depth": info.bvh_depth,
@@ -330,7 +334,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     renderer.close()
-    if world > 1:
+    if grouped:
         dist.barrier()  # rank 0 is still measuring its roofline figures: nobody tears the group down before it is done
         dist.destroy_process_group()
 

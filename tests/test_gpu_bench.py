@@ -45,3 +45,22 @@ def test_two_ranks_launch_themselves_and_share_the_sample_range():
     weak = run_bench(["--gpus", "2", "--config", "1", "--spp", "4", "--scaling", "weak", "--steps", "1", "--warmup", "0"], {"RRT_BENCH_REHEARSAL": "1"})
     assert weak["scaling"] == "weak" and weak["config"]["spp_total"] == 8 and weak["config"]["spp_per_gpu"] == 4
     assert round(weak["rays_per_sample"] * 711 * 400 * 8) == round(one["rays_per_sample"] * 711 * 400 * 8)
+
+
+def test_one_rank_under_the_launcher_runs_the_rccl_calls():
+    """The driver's multi-GPU runs use the nccl (= RCCL) backend, which this one-GPU box cannot run with two ranks.  A
+    group of one rank still initialises RCCL, reduces the device buffer the kernel wrote and all-reduces the timings: the
+    calls of the N > 1 path, with the library and PyTorch in one process."""
+    env = dict(os.environ)
+    env.update({"RRT_BENCH_FORCE_GROUP": "1", "MASTER_ADDR": "127.0.0.1"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", "1", "--spp", "8", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["process_group"] == "nccl" and out["n_gpus"] == 1 and out["value"] > 0
+    one = run_bench(["--config", "1", "--spp", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
+    assert round(out["rays_per_sample"] * 711 * 400 * 8) == round(one["rays_per_sample"] * 711 * 400 * 8)
