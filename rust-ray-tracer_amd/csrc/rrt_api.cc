@@ -303,6 +303,7 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
     S.root = device_ref(hs.root);
     S.has_instances = hs.has_instances ? 1u : 0u;
     S.unroll_shift = hs.unroll_shift;
+    S.inst_count = (uint32_t)hs.insts.size();
     S.light_weight = S.light_count ? 1.0f / (float)S.light_count : 0.0f;
     S.light_zone = S.light_count ? (uint32_t)((0x100000000ull) % S.light_count) : 0u;
     S.cam = hs.cam;

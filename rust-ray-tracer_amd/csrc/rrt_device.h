@@ -352,6 +352,8 @@ struct Trav {
 // registers per lane are what separates the instanced kernels from the occupancy of the flat ones.  A walk that is
 // complete has popped every exit marker: its registers hold the world ray again.
 typedef __attribute__((address_space(3))) float lds_float;
+typedef float vec4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) vec4f lds_float4;
 __device__ __forceinline__ void wray_park(lds_float* w, int stride, V3 o, V3 d) {
     w[0] = o.x; w[stride] = o.y; w[2 * stride] = o.z; w[3 * stride] = d.x; w[4 * stride] = d.y; w[5 * stride] = d.z;
 }
@@ -562,10 +564,12 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
 // One primitive per step keeps the cost of a pass the same for every lane, whatever its leaf holds.
 // Precondition: T.cur is negative and not REF_DONE.
 // PAIR: a triangle leaf with at least two records left has two of them tested in one step.
+// xf_lds (MODE_UNROLLED): the workgroup's LDS copy of the instance transforms, two float4 per slot (slot 0: identity), or
+// nullptr when the table is read from device memory.
 template <int MODE, bool COUNT, int K = 0, bool PAIR = false>
 __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float tmin, int stride, Trav& T,
                                           TraceCounters& cnt, lds_int* lim = nullptr, int* deep = nullptr,
-                                          lds_float* wray = nullptr) {
+                                          lds_float* wray = nullptr, const lds_float4* xf_lds = nullptr) {
     constexpr bool INST = MODE == MODE_TWO_LEVEL;
     const uint32_t ref = (uint32_t)T.cur;
     const uint32_t kind = (ref >> 28) & 7u;
@@ -581,8 +585,18 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
         first_mask = (1u << S.unroll_shift) - 1u;
         tri_inst = kind == KIND_TRI ? (int32_t)(first >> S.unroll_shift) - 1 : -1;
         first &= kind == KIND_TRI ? first_mask : REF_OFFSET_MASK;
-        const float4 x0 = reinterpret_cast<const float4*>(&S.insts[tri_inst])[0];
-        const float4 x1 = reinterpret_cast<const float4*>(&S.insts[tri_inst])[1];
+        // (the record comes from the workgroup's LDS copy of the table when the kernel keeps one: a load through the
+        // vector L1 takes its address unit 16 cycles whatever the number of lanes, and that unit is as busy as the SIMDs)
+        float4 x0, x1;
+        if (xf_lds != nullptr) {
+            const lds_float4* e = xf_lds + 2 * (tri_inst + 1);
+            const vec4f e0 = e[0], e1 = e[1];
+            x0 = make_float4(e0.x, e0.y, e0.z, e0.w);
+            x1 = make_float4(e1.x, e1.y, e1.z, e1.w);
+        } else {
+            x0 = reinterpret_cast<const float4*>(&S.insts[tri_inst])[0];
+            x1 = reinterpret_cast<const float4*>(&S.insts[tri_inst])[1];
+        }
         const V3 m = o - v3(x0.x, x0.y, x0.z);
         const V3 to = v3(x1.y * m.x - x1.x * m.z, m.y, x1.x * m.x + x1.y * m.z);
         const V3 td = v3(x1.y * d.x - x1.x * d.z, d.y, x1.x * d.x + x1.y * d.z);

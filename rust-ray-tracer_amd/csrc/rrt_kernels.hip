@@ -34,6 +34,7 @@ static constexpr int RENDER_STACK = 16;   // traversal stack entries per lane th
 #ifndef RRT_INST_STACK
 #define RRT_INST_STACK 16  // ... and the traversal stack entries per lane they keep in LDS
 #endif
+static constexpr int XF_LDS_SLOTS = 128;  // unrolled scenes: instance transforms (identity + instances) a workgroup of k_render keeps in LDS
 static constexpr uint32_t N_QUEUES = 8;   // workgroup ids congruent mod 8 are dealt to one XCD and share its L2
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -68,6 +69,16 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
     __shared__ int s_stack[K * RENDER_BLOCK];
     __shared__ float s_wray[INST ? 6 * RENDER_BLOCK : 1];
     __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 16];  // per wavefront: the records of its two work items
+    // Unrolled scenes: the instance transforms a triangle leaf needs (offset, sin, cos: the first 32 bytes of a record)
+    // are copied to LDS once per workgroup when they fit, slot 0 = the identity record in front of the table.
+    __shared__ vec4f s_xf[MODE == MODE_UNROLLED ? 2 * XF_LDS_SLOTS : 1];
+    const lds_float4* xf_lds = nullptr;
+    if (MODE == MODE_UNROLLED && S.inst_count + 1u <= (uint32_t)XF_LDS_SLOTS) {
+        const vec4f* src = reinterpret_cast<const vec4f*>(S.insts - 1);  // four 16-byte quarters per 64-byte record
+        for (uint32_t i = threadIdx.x; i < 2u * (S.inst_count + 1u); i += RENDER_BLOCK) s_xf[i] = src[(i >> 1) * 4u + (i & 1u)];
+        __syncthreads();
+        xf_lds = (const lds_float4*)s_xf;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     lds_int* stack = (lds_int*)(s_stack + threadIdx.x);
     lds_float* wray = INST ? (lds_float*)(s_wray + threadIdx.x) : nullptr;
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                             trav_nodes<MODE, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         }
                     }
-                    if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray);
+                    if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
                 }
                 // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
                 if (has_ray && T.cur == REF_DONE) {
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         trav_nodes<MODE, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                     }
                 }
-                if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray);
+                if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
             }
 
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its

@@ -149,6 +149,7 @@ struct SceneDev {
     uint32_t light_count;
     int32_t root;       // root node of the top-level BVH
     uint32_t has_instances;   // instance leaves in the top-level BVH (two-level walk)
+    uint32_t inst_count;      // instance records
     uint32_t unroll_shift;    // != 0: instances unrolled into one world-space tree; a triangle leaf's 25-bit field is
                               // (instance slot << unroll_shift) | first record, slot 0 = not instanced
     uint32_t light_zone;  // 2^32 mod light_count (rejection zone of the uniform light pick)
