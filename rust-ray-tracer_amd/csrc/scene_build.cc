@@ -576,8 +576,12 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
             if (ob.type == RRT_OBJ_TRIANGLES) world_tris += ob.count;
             if (ob.type != RRT_OBJ_INSTANCE) continue;
             if (ob.count != 1u || ob.first >= d->instance_count || d->instances[ob.first].mesh >= d->mesh_count) { ok = false; break; }  // reported by expand()
-            const Expander::MeshInfo& mi = meshes[d->instances[ob.first].mesh];
-            ok = mi.host_built && mi.tri_only && mi.tri_count > 0u;
+            const rrt_instance& in = d->instances[ob.first];
+            const Expander::MeshInfo& mi = meshes[in.mesh];
+            // (the world boxes take the instance's point map for the inverse of its ray map, which it is for a rotation:
+            // an instance whose sin / cos pair is not one keeps the two-level walk, which makes no such assumption)
+            const double norm = (double)in.sin_theta * in.sin_theta + (double)in.cos_theta * in.cos_theta;
+            ok = mi.host_built && mi.tri_only && mi.tri_count > 0u && std::fabs(norm - 1.0) < 1e-5;
             copy_nodes += mi.node_count;
         }
         uint64_t max_nodes = 1ull << 24;

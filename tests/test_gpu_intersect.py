@@ -258,6 +258,48 @@ def test_random_soups_with_hostile_coordinates(rrt, oracle, monkeypatch, device_
         r.close()
 
 
+def test_unrolled_instances_with_hostile_coordinates(rrt, oracle):
+    """Unrolled instances put world-space boxes around triangles that are tested in object space, with the ray moved
+    there in f32: the boxes' pad has to cover the rounding of that move.  Small meshes far from the origin, far from
+    each other and rotated by awkward angles, rays from inside, from far outside and along the axes; the two-level
+    form on the same rays must give the same records, and both the oracle's."""
+    g = np.random.default_rng(77)
+    for scale, spread in ((1.0, 30.0), (0.05, 2000.0), (20.0, 1e4), (1e-2, 5.0)):
+        s = rrt.Scene()
+        m = s.add_material(rrt.Lambertian(0.5, 0.5, 0.5))
+        mesh = s.new_mesh()
+        n = 600
+        centres = g.uniform(-1, 1, (n, 1, 3)) * scale
+        tris = (centres + g.normal(0, 0.05 * scale, (n, 3, 3))).astype(np.float32)
+        s.add_triangles(tris, m, mesh=mesh)
+        mi = s.finish_mesh(mesh)
+        offsets = g.uniform(-1, 1, (10, 3)) * spread
+        angles = [0.0, 90.0, 180.0, 270.0, 45.0, 1e-3, 359.999, 33.3, 123.4, 271.7]
+        for off, ang in zip(offsets, angles):
+            s.add_instance(mi, angle_deg=ang, offset=tuple(float(x) for x in off))
+        s.add_triangles((g.normal(0, 1, (4, 3, 3)) * spread).astype(np.float32), m)  # a few huge top-level triangles
+        s.camera = rrt.Camera(1.0, 40.0, np.float32([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 3 * spread]]))
+        a, b = rrt.Renderer(), rrt.Renderer(unroll_instances=False)
+        assert a.upload(s).unrolled_instances == 10 and b.upload(s).unrolled_instances == 0
+        k = 512
+        which = g.integers(0, 10, 3 * k)
+        target = offsets[which] + g.uniform(-1, 1, (3 * k, 3)) * scale
+        inside = offsets[which[:k]] + g.uniform(-1, 1, (k, 3)) * scale
+        far = g.normal(0, 1, (k, 3))
+        far = far / np.linalg.norm(far, axis=1, keepdims=True) * 4 * spread
+        axis = np.zeros((k, 3))
+        axis[np.arange(k), g.integers(0, 3, k)] = g.choice([-1.0, 1.0], k)
+        origins = np.concatenate([inside, far, target[2 * k:] - axis * 3 * scale])
+        dirs = np.concatenate([g.normal(0, 1, (k, 3)), target[k:2 * k] - far, axis])
+        rays = helpers.make_rays(origins.astype(np.float32), dirs.astype(np.float32))
+        ga, gb, want = a.intersect(rays, t_min=1e-4 * scale), b.intersect(rays, t_min=1e-4 * scale), oracle.OracleScene(s).intersect(rays, t_min=1e-4 * scale)
+        assert (want["prim_id"] >= 0).mean() > 0.02, (scale, spread)
+        assert np.array_equal(ga, gb), (scale, spread)
+        helpers.assert_hits_match(ga, want)
+        a.close()
+        b.close()
+
+
 def test_scene_fed_to_both_sides_is_itself_checked_on_the_box(rrt, oracle):
     """The oracle and the GPU path both consume the scene the product's glTF loader emits, so a loader error would be
     invisible to the comparisons above.  Here the loader's triangles are compared, on the box that runs the GPU

@@ -75,6 +75,8 @@ def main():
             row[rename[k]] = v
     if "fetch_size_kb" in row and "write_size_kb" in row:
         row["hbm_bytes"] = (2.0 * row["fetch_size_kb"] + row["write_size_kb"]) * 1024.0
+    if row.get("sq_waves"):
+        row["waves_per_simd"] = row["sq_waves"] / 1024.0
     if row.get("sq_active_inst_valu"):
         row["lane_util_hw"] = row["sq_thread_cycles_valu"] / (64.0 * row["sq_active_inst_valu"])
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs: the kernel's cycles are an eighth of it
