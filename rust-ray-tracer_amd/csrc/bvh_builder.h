@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <vector>
 
+#include "../../include/rrt_ffi.h"
 #include "rrt_layout.h"
 
 namespace rrt {
@@ -19,6 +20,14 @@ struct BuildPrim {
     float bmin[3], bmax[3];  // bounding box (reference formula, plus the builder's conservative pad)
     uint32_t kind;           // KIND_TRI / KIND_SPHERE / KIND_RECT / KIND_INST
     uint32_t index;          // record index in the typed array (triangles: index into the UNORDERED list)
+};
+
+// A run of the caller's triangles that the GPU turns into records and boxes itself (host memory, valid until the build
+// returns); ids are id0, id0 + 1, ...
+struct RawTriRun {
+    const rrt_triangle* src;
+    uint32_t count;
+    uint32_t id0;
 };
 
 struct BuildResult {

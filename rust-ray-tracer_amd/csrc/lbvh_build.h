@@ -26,10 +26,15 @@ struct LbvhResult {
 // cluster_size > 0: the radix tree is cut where subtrees hold at most that many primitives, and the levels above the
 // cut -- where splitting at Morton code boundaries costs the most -- are rebuilt on the host with the surface-area
 // heuristic over the subtrees' boxes (a few per cent of the primitives' number; `threads` host threads).
+// runs / n_runs (may be empty): triangles of the BVH that the host has NOT expanded.  The GPU reads the caller's
+// vertices, writes their records (reference src/geometry/triangle.rs:17-18,28-29: v0 and the two edges) to
+// d_tris[tri_base + ordinal] and their boxes (triangle.rs:82-94, widened by `pad` like the host's) behind the n
+// host-expanded primitives; their ordinals follow those of the host-expanded triangles, in run order.  tri_count counts
+// both kinds.
 // Blocks until the build is complete.
 hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QNode* d_nodes, uint32_t node_base,
                       TriRec* d_tris, uint32_t tri_base, uint32_t tri_count, uint32_t max_depth, uint32_t cluster_size,
-                      unsigned threads, LbvhResult* out);
+                      unsigned threads, LbvhResult* out, const RawTriRun* runs = nullptr, size_t n_runs = 0, float pad = 0.f);
 
 }  // namespace rrt
 #endif

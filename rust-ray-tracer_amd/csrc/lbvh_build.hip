@@ -80,6 +80,32 @@ __global__ void k_morton(const BuildPrim* __restrict__ prims, uint32_t n, Grid g
     vals[i] = i;
 }
 
+// The caller's triangles -> records and boxes, with the host expander's arithmetic (scene_build.cc): record = v0 and the
+// edges v1 - v0, v2 - v0 (reference src/geometry/triangle.rs:28-29), box = the vertices' extent -+ 1e-4
+// (triangle.rs:82-94) -+ the builder's pad.  Triangle i of the run gets ordinal ordinal0 + i.
+__global__ void k_expand_tris(const rrt_triangle* __restrict__ src, uint32_t count, uint32_t id0, uint32_t ordinal0, float pad,
+                              BuildPrim* __restrict__ prims, TriRec* __restrict__ tris) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= count) return;
+    const rrt_triangle t = src[i];
+    TriRec rec;
+    BuildPrim p;
+    for (int a = 0; a < 3; ++a) {
+        rec.v0[a] = t.v0[a];
+        rec.e1[a] = t.v1[a] - t.v0[a];
+        rec.e2[a] = t.v2[a] - t.v0[a];
+        p.bmin[a] = (fminf(t.v0[a], fminf(t.v1[a], t.v2[a])) - 0.0001f) - pad;
+        p.bmax[a] = (fmaxf(t.v0[a], fmaxf(t.v1[a], t.v2[a])) + 0.0001f) + pad;
+    }
+    rec.id = id0 + i;
+    rec.material = t.material;
+    rec.pad = 0u;
+    p.kind = KIND_TRI;
+    p.index = ordinal0 + i;
+    prims[i] = p;
+    tris[ordinal0 + i] = rec;
+}
+
 __global__ void k_gather(const BuildPrim* __restrict__ prims, const uint32_t* __restrict__ vals, uint32_t n,
                          LeafInfo* __restrict__ leaf, uint32_t* __restrict__ is_tri) {
     const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
@@ -354,14 +380,20 @@ static hipError_t rebuild_top(const uint32_t* d_upper, const Cluster* d_clusters
     return hipSuccess;
 }
 
-hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QNode* d_nodes, uint32_t node_base,
+hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n_host, const Grid& grid, QNode* d_nodes, uint32_t node_base,
                       TriRec* d_tris, uint32_t tri_base, uint32_t tri_count, uint32_t max_depth, uint32_t cluster_size,
-                      unsigned threads, LbvhResult* out) {
+                      unsigned threads, LbvhResult* out, const RawTriRun* runs, size_t n_runs, float pad) {
     out->depth = 0;
     out->build_ms = 0.f;
     out->clusters = 0;
     out->top_ms = 0.f;
-    if (n < 2u || n > REF_OFFSET_MASK) return hipErrorInvalidValue;
+    uint64_t raw_tris = 0, largest_run = 0;
+    for (size_t r = 0; r < n_runs; ++r) {
+        raw_tris += runs[r].count;
+        largest_run = std::max<uint64_t>(largest_run, runs[r].count);
+    }
+    if ((uint64_t)n_host + raw_tris < 2u || (uint64_t)n_host + raw_tris > REF_OFFSET_MASK || raw_tris > tri_count) return hipErrorInvalidValue;
+    const uint32_t n = n_host + (uint32_t)raw_tris;
     Buffers B;
     BuildPrim* d_prims;
     unsigned long long *keys_a, *keys_b;
@@ -402,8 +434,26 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n, const Grid& grid, QN
     LBVH_TRY(hipEventCreate(&B.e0));
     LBVH_TRY(hipEventCreate(&B.e1));
 
-    LBVH_TRY(hipMemcpy(d_prims, h_prims, (size_t)n * sizeof(BuildPrim), hipMemcpyHostToDevice));
+    if (n_host) LBVH_TRY(hipMemcpy(d_prims, h_prims, (size_t)n_host * sizeof(BuildPrim), hipMemcpyHostToDevice));
     const hipStream_t s = (hipStream_t)0;
+    if (raw_tris) {
+        // the caller's vertices go up run by run through one staging buffer; records and boxes are made here
+        rrt_triangle* staging;
+        LBVH_TRY(B.alloc(&staging, (size_t)largest_run));
+        uint32_t ordinal = tri_count - (uint32_t)raw_tris;  // the host-expanded triangles come first
+        uint32_t at = n_host;
+        for (size_t r = 0; r < n_runs; ++r) {
+            const RawTriRun& run = runs[r];
+            if (run.count == 0u) continue;
+            LBVH_TRY(hipMemcpy(staging, run.src, (size_t)run.count * sizeof(rrt_triangle), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_expand_tris, dim3((run.count + BLOCK - 1u) / BLOCK), dim3(BLOCK), 0, s, staging, run.count, run.id0, ordinal,
+                               pad, d_prims + at, d_tris + tri_base);
+            LBVH_TRY(hipGetLastError());
+            LBVH_TRY(hipStreamSynchronize(s));  // the staging buffer is reused by the next run
+            ordinal += run.count;
+            at += run.count;
+        }
+    }
     const unsigned blocks = (n + BLOCK - 1u) / BLOCK, blocks1 = (n + 1u + BLOCK - 1u) / BLOCK;
     LBVH_TRY(hipEventRecord(B.e0, s));
     hipLaunchKernelGGL(k_morton, dim3(blocks), dim3(BLOCK), 0, s, d_prims, n, grid, keys_a, vals_a);

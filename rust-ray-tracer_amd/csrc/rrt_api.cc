@@ -102,10 +102,11 @@ std::vector<InstRec> insts_with_identity(const std::vector<InstRec>& insts) {
     return v;
 }
 
+// `tail`: records behind v that exist on the device only (zeroed here, written by the GPU builder).
 template <typename T>
-rrt_status upload(rrt_ctx* c, const std::vector<T>& v, void** dst, uint64_t& total) {
+rrt_status upload(rrt_ctx* c, const std::vector<T>& v, void** dst, uint64_t& total, size_t tail = 0) {
     // every array gets at least one record so that kernels never see a NULL base
-    const size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+    const size_t bytes = std::max<size_t>(v.size() + tail, 1) * sizeof(T);
     RRT_HIP(c, hipMalloc(dst, bytes));
     RRT_HIP(c, hipMemset(*dst, 0, bytes));
     if (!v.empty()) RRT_HIP(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -250,7 +251,7 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
         RRT_HIP(c, hipDeviceSynchronize());
         free_scene(c);
         total = 0;
-        if ((st = upload(c, hs.qnodes, &c->d_nodes, total)) != RRT_OK || (st = upload(c, hs.tris, &c->d_tris, total)) != RRT_OK ||
+        if ((st = upload(c, hs.qnodes, &c->d_nodes, total, hs.tail_nodes)) != RRT_OK || (st = upload(c, hs.tris, &c->d_tris, total, hs.tail_tris)) != RRT_OK ||
             (st = upload(c, hs.spheres, &c->d_spheres, total)) != RRT_OK || (st = upload(c, hs.rects, &c->d_rects, total)) != RRT_OK ||
             (st = upload(c, insts_with_identity(hs.insts), &c->d_insts, total)) != RRT_OK || (st = upload(c, hs.mats, &c->d_mats, total)) != RRT_OK ||
             (st = upload(c, hs.lights, &c->d_lights, total)) != RRT_OK) {
@@ -271,7 +272,8 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
             uint32_t cluster = 16u;
             if (const char* e = std::getenv("RRT_LBVH_CLUSTER")) cluster = (uint32_t)std::max(0, std::atoi(e));
             const hipError_t e = lbvh_build(db.prims.data(), (uint32_t)db.prims.size(), db.grid, (QNode*)c->d_nodes, db.node_base,
-                                            (TriRec*)c->d_tris, db.tri_base, db.tri_count, budget, cluster, build_threads(), &r);
+                                            (TriRec*)c->d_tris, db.tri_base, db.tri_count, budget, cluster, build_threads(), &r,
+                                            db.raw_runs.data(), db.raw_runs.size(), db.pad);
             if (e != hipSuccess) {
                 free_scene(c);
                 return hip_fail(c, e, "rrt_scene_upload: GPU BVH build");
@@ -314,8 +316,8 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
     S.grid = hs.grid;
 
     c->info.prim_count = hs.prim_count;
-    c->info.node_count = (uint32_t)hs.qnodes.size();
-    c->info.tri_count = (uint32_t)hs.tris.size();
+    c->info.node_count = (uint32_t)hs.qnodes.size() + hs.tail_nodes;
+    c->info.tri_count = (uint32_t)hs.tris.size() + hs.tail_tris;
     c->info.bvh_depth = hs.depth;
     c->info.unrolled_instances = hs.unrolled_instances;
     c->info.device_bytes = total;
@@ -349,12 +351,12 @@ rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
     if (st != RRT_OK) return set_err(nullptr, st, "rrt_scene_check: " + err);
     std::memset(out, 0, sizeof *out);
     out->prim_count = hs.prim_count;
-    out->node_count = (uint32_t)hs.qnodes.size();
-    out->tri_count = (uint32_t)hs.tris.size();
+    out->node_count = (uint32_t)hs.qnodes.size() + hs.tail_nodes;
+    out->tri_count = (uint32_t)hs.tris.size() + hs.tail_tris;
     out->bvh_depth = hs.depth;
     out->unrolled_instances = hs.unrolled_instances;
     auto sz = [](size_t n, size_t rec) { return (uint64_t)(n ? n : 1) * rec; };
-    out->device_bytes = sz(hs.qnodes.size(), sizeof(QNode)) + sz(hs.tris.size(), sizeof(TriRec)) + sz(hs.spheres.size(), sizeof(SphereRec)) +
+    out->device_bytes = sz(hs.qnodes.size() + hs.tail_nodes, sizeof(QNode)) + sz(hs.tris.size() + hs.tail_tris, sizeof(TriRec)) + sz(hs.spheres.size(), sizeof(SphereRec)) +
                         sz(hs.rects.size(), sizeof(RectRec)) + sz(hs.insts.size() + 1u, sizeof(InstRec)) + sz(hs.mats.size(), sizeof(MatRec)) +
                         sz(hs.lights.size(), sizeof(LightRec));
     out->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -99,12 +99,18 @@ struct Expander {
     // list is expanded; empty when the scene is not unrolled.
     std::vector<std::array<float, 6>> inst_world_box;
     std::vector<uint32_t> inst_of_record;  // per InstRec pushed: the index of its rrt_instance
+    // Top-level triangle runs left to the GPU builder (records and boxes are made there): the runs, their triangle
+    // count and the extent of their vertices.
+    bool raw_triangles = false;
+    std::vector<RawTriRun> raw_runs;
+    uint32_t raw_tris = 0;
+    float raw_mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, raw_mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     bool expand(const rrt_object* objs, uint32_t n_objs, uint32_t& id, std::vector<BuildPrim>& prims,
                 const std::vector<MeshInfo>* meshes) {
         {   // one growth of the big arrays instead of one per run (a scene may list its triangles in many runs)
             size_t n_tris = 0, n_other = 0;
             for (uint32_t oi = 0; oi < n_objs; ++oi) {
-                if (objs[oi].type == RRT_OBJ_TRIANGLES) n_tris += objs[oi].count;
+                if (objs[oi].type == RRT_OBJ_TRIANGLES) n_tris += (raw_triangles && meshes) ? 0u : objs[oi].count;
                 else n_other += objs[oi].type == RRT_OBJ_CUBOIDS ? 6u * (size_t)objs[oi].count : objs[oi].count;
             }
             tri_src.reserve(tri_src.size() + n_tris);
@@ -115,6 +121,35 @@ struct Expander {
             switch (ob.type) {
                 case RRT_OBJ_TRIANGLES: {
                     if ((uint64_t)ob.first + ob.count > d->triangle_count) return fail("triangle run out of range");
+                    if (raw_triangles && meshes) {
+                        // left to the GPU builder: the host only checks the material indices and takes the vertices' extent
+                        std::atomic<bool> bad{false};
+                        constexpr unsigned MAX_PIECES = 64;
+                        float pmn[MAX_PIECES][3], pmx[MAX_PIECES][3];
+                        for (unsigned k = 0; k < MAX_PIECES; ++k)
+                            for (int a = 0; a < 3; ++a) { pmn[k][a] = FLT_MAX; pmx[k][a] = -FLT_MAX; }
+                        std::atomic<unsigned> piece{0};
+                        parallel_for(ob.count, threads, [&](uint32_t lo, uint32_t hi) {
+                            const unsigned k = piece.fetch_add(1) % MAX_PIECES;
+                            float lmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, lmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+                            for (uint32_t i = lo; i < hi; ++i) {
+                                const rrt_triangle& t = d->triangles[ob.first + i];
+                                if (t.material >= d->material_count) bad.store(true, std::memory_order_relaxed);
+                                for (int a = 0; a < 3; ++a) {
+                                    lmn[a] = std::min(lmn[a], std::min(t.v0[a], std::min(t.v1[a], t.v2[a])));
+                                    lmx[a] = std::max(lmx[a], std::max(t.v0[a], std::max(t.v1[a], t.v2[a])));
+                                }
+                            }
+                            for (int a = 0; a < 3; ++a) { pmn[k][a] = std::min(pmn[k][a], lmn[a]); pmx[k][a] = std::max(pmx[k][a], lmx[a]); }
+                        });
+                        if (bad.load()) return fail("triangle material index out of range");
+                        for (unsigned k = 0; k < MAX_PIECES; ++k)
+                            for (int a = 0; a < 3; ++a) { raw_mn[a] = std::min(raw_mn[a], pmn[k][a]); raw_mx[a] = std::max(raw_mx[a], pmx[k][a]); }
+                        raw_runs.push_back(RawTriRun{d->triangles + ob.first, ob.count, id});
+                        raw_tris += ob.count;
+                        id += ob.count;
+                        break;
+                    }
                     // large runs are filled by several threads: every triangle has its slot and its id up front
                     const size_t src0 = tri_src.size(), prim0 = prims.size();
                     const uint32_t id0 = id;
@@ -382,8 +417,13 @@ static uint32_t build_instance_tree(std::vector<BuildPrim>& prims, const std::ve
 }
 
 // Reserves nodes and triangle slots for a BVH the GPU will build; returns its root box in mn/mx.
+// raw_runs (top level only, may be null): triangle runs the host has not expanded; they join the BVH as its last
+// primitives and triangle ordinals, their node range and records exist on the device only (hs.tail_nodes / tail_tris),
+// and the extent of their vertices [raw_mn, raw_mx] enters the root box with the pads every triangle box carries.
 static void defer_build(HostScene& hs, std::vector<BuildPrim>& prims, std::vector<uint32_t>& tri_order, uint32_t budget,
-                        int mesh, float* mn, float* mx, int32_t& root, Grid& grid, unsigned threads) {
+                        int mesh, float* mn, float* mx, int32_t& root, Grid& grid, unsigned threads,
+                        std::vector<RawTriRun>* raw_runs = nullptr, uint32_t raw_tris = 0, const float* raw_mn = nullptr,
+                        const float* raw_mx = nullptr, float pad = 0.f) {
     DeferredBuild db;
     db.node_base = (uint32_t)hs.qnodes.size();
     db.tri_base = (uint32_t)tri_order.size();
@@ -420,10 +460,24 @@ static void defer_build(HostScene& hs, std::vector<BuildPrim>& prims, std::vecto
         }
     }
     db.tri_count = ordinal;
+    if (raw_runs && raw_tris) {
+        for (int a = 0; a < 3; ++a) {  // the same two steps as a triangle's own box: tri_box(), then widen()
+            mn[a] = std::min(mn[a], (raw_mn[a] - 0.0001f) - pad);
+            mx[a] = std::max(mx[a], (raw_mx[a] + 0.0001f) + pad);
+        }
+        db.raw_runs.swap(*raw_runs);
+        db.raw_tris = raw_tris;
+        db.pad = pad;
+        db.tri_count += raw_tris;
+        hs.tail_nodes = (uint32_t)prims.size() + raw_tris;  // this BVH's node range: on the device only
+        hs.tail_tris = raw_tris;
+    }
     db.grid = grid = make_grid(mn, mx);
-    QNode blank;
-    std::memset(&blank, 0, sizeof blank);
-    hs.qnodes.resize(hs.qnodes.size() + prims.size(), blank);  // the range the GPU builder fills (uploaded blank)
+    if (!db.raw_tris) {
+        QNode blank;
+        std::memset(&blank, 0, sizeof blank);
+        hs.qnodes.resize(hs.qnodes.size() + prims.size(), blank);  // the range the GPU builder fills (uploaded blank)
+    }
     root = (int32_t)db.node_base;  // the radix tree's root is its first inner node
     db.prims.swap(prims);
     hs.deferred.push_back(std::move(db));
@@ -618,13 +672,24 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     }
     std::vector<BuildPrim> prims;
     uint32_t id = 0;
+    {
+        // a top level the GPU builder will build leaves its triangle runs unexpanded: the GPU makes records and boxes
+        uint64_t world_prims = 0, world_tris = 0;
+        for (uint32_t i = 0; i < d->world_count; ++i) {
+            world_prims += d->world[i].type == RRT_OBJ_CUBOIDS ? 6ull * d->world[i].count : d->world[i].count;
+            if (d->world[i].type == RRT_OBJ_TRIANGLES) world_tris += d->world[i].count;
+        }
+        ex.raw_triangles = device_build_min != 0u && world_prims >= device_build_min && world_tris > 0u && world_prims <= REF_OFFSET_MASK &&
+                           std::getenv("RRT_HOST_EXPAND") == nullptr;
+    }
     if (!ex.expand(d->world, d->world_count, id, prims, &meshes)) return RRT_ERR_INVALID;
     trace.mark("world list expanded");
     hs.prim_count = id;
     hs.deepest_mesh = deepest_mesh;
-    if (device_build_min && prims.size() >= device_build_min) {
+    if (device_build_min && prims.size() + ex.raw_tris >= device_build_min) {
         float mn[3], mx[3];
-        defer_build(hs, prims, tri_order, top_budget, -1, mn, mx, hs.root, hs.grid, threads);
+        defer_build(hs, prims, tri_order, top_budget, -1, mn, mx, hs.root, hs.grid, threads, &ex.raw_runs, ex.raw_tris, ex.raw_mn,
+                    ex.raw_mx, ex.pad);
         hs.top_depth = 0;
         hs.depth = 0;
     } else {
@@ -684,8 +749,8 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     }
     trace.mark("top-level BVH (or deferral)");
     hs.has_instances = !hs.insts.empty() && hs.unroll_shift == 0u;
-    if (tri_order.size() > REF_OFFSET_MASK) { err = "too many triangles"; return RRT_ERR_INVALID; }
-    if (hs.qnodes.size() > (size_t)REF_OFFSET_MASK) { err = "too many BVH nodes"; return RRT_ERR_INVALID; }  // device_ref: byte offsets below 2^30
+    if (tri_order.size() + (size_t)hs.tail_tris > REF_OFFSET_MASK) { err = "too many triangles"; return RRT_ERR_INVALID; }
+    if (hs.qnodes.size() + (size_t)hs.tail_nodes > (size_t)REF_OFFSET_MASK) { err = "too many BVH nodes"; return RRT_ERR_INVALID; }  // device_ref: byte offsets below 2^30
 
     hs.tris.resize(tri_order.size());
     parallel_for((uint32_t)tri_order.size(), threads, [&](uint32_t lo, uint32_t hi) {

@@ -21,6 +21,12 @@ struct DeferredBuild {
     uint32_t budget = 0;   // node levels the BVH may have
     int mesh = -1;         // mesh index, -1: the top-level BVH
     Grid grid{};
+    // Triangle runs the host has not expanded (top-level BVH only): the GPU makes their records and boxes from the
+    // caller's vertices, which must stay valid until the upload is complete.  They are primitives prims.size() ..
+    // prims.size() + raw_tris - 1 of the BVH and its last raw_tris triangle ordinals; `pad` widens their boxes.
+    std::vector<RawTriRun> raw_runs;
+    uint32_t raw_tris = 0;
+    float pad = 0.f;
 };
 
 struct HostScene {
@@ -38,6 +44,9 @@ struct HostScene {
     uint32_t top_depth = 0;        // node levels of the top-level BVH (0 while its build is deferred)
     uint32_t deepest_mesh = 0;     // node levels of the deepest host-built mesh BVH
     std::vector<DeferredBuild> deferred;
+    // What exists on the device only, behind the arrays above: the node range of a deferred top-level BVH over raw
+    // triangle runs, and those triangles' records (both written by the GPU builder).
+    uint32_t tail_nodes = 0, tail_tris = 0;
     bool has_instances = false;    // instance leaves in the top-level BVH (two-level walk)
     uint32_t unroll_shift = 0;     // != 0: instances unrolled into the top-level tree (SceneDev::unroll_shift)
     uint32_t unrolled_instances = 0;
