@@ -8,6 +8,8 @@
 #include <cmath>
 #include <cstring>
 #include <future>
+#include <thread>
+#include <vector>
 
 namespace rrt {
 namespace {
@@ -80,18 +82,60 @@ struct Builder {
         return c;
     }
 
+    unsigned total_threads = 1;
+
+    // body(piece, lo, hi) over [b, e) in `pieces` contiguous pieces, one thread each
+    template <typename F>
+    static void in_pieces(uint32_t b, uint32_t e, unsigned pieces, F body) {
+        if (pieces <= 1u) {
+            body(0u, b, e);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const uint64_t n = e - b;
+        for (unsigned k = 0; k < pieces; ++k) {
+            const uint32_t lo = b + (uint32_t)(n * k / pieces), hi = b + (uint32_t)(n * (k + 1) / pieces);
+            pool.emplace_back([=, &body]() { body(k, lo, hi); });
+        }
+        for (std::thread& t : pool) t.join();
+    }
+
     Child build_range(uint32_t b, uint32_t e, uint32_t budget, int task_depth) {
         const uint32_t n = e - b;
+        // The passes over a large range (bounds, then the bins of all three axes) run on several threads: at the top
+        // of a ten-million-primitive build they are most of the time, and the ranges below are not yet many enough to
+        // keep the threads busy.  Minima, maxima and counts do not depend on how the range is cut, so the tree is the
+        // same for any number of threads.
+        constexpr unsigned MAX_PIECES = 32;
+        unsigned pieces = 1;
+        if (n >= (1u << 17) && total_threads > 1u) pieces = std::min(std::min(total_threads >> std::min(task_depth, 4), MAX_PIECES), n >> 15);
+        if (pieces < 1u) pieces = 1u;
         Box box;
         box.reset();
         Box cbox;
         cbox.reset();
         bool all_tri = true;
-        for (uint32_t i = b; i < e; ++i) {
-            box.grow(prims[i].bmin, prims[i].bmax);
-            float c[3] = {centroid(prims[i], 0), centroid(prims[i], 1), centroid(prims[i], 2)};
-            cbox.grow(c, c);
-            all_tri = all_tri && prims[i].kind == KIND_TRI;
+        {
+            Box pbox[MAX_PIECES], pcbox[MAX_PIECES];
+            bool ptri[MAX_PIECES];
+            in_pieces(b, e, pieces, [&](unsigned k, uint32_t lo, uint32_t hi) {
+                Box bx, cb;
+                bx.reset();
+                cb.reset();
+                bool tri = true;
+                for (uint32_t i = lo; i < hi; ++i) {
+                    bx.grow(prims[i].bmin, prims[i].bmax);
+                    float c[3] = {centroid(prims[i], 0), centroid(prims[i], 1), centroid(prims[i], 2)};
+                    cb.grow(c, c);
+                    tri = tri && prims[i].kind == KIND_TRI;
+                }
+                pbox[k] = bx; pcbox[k] = cb; ptri[k] = tri;
+            });
+            for (unsigned k = 0; k < pieces; ++k) {
+                box.grow(pbox[k]);
+                cbox.grow(pcbox[k]);
+                all_tri = all_tri && ptri[k];
+            }
         }
         if (n == 1) return make_leaf(b, e, box);
 
@@ -101,19 +145,41 @@ struct Builder {
         int best_axis = -1, best_bin = -1;
         const float ext[3] = {cbox.mx[0] - cbox.mn[0], cbox.mx[1] - cbox.mn[1], cbox.mx[2] - cbox.mn[2]};
 
-        // --- binned SAH over the three axes
+        // --- binned SAH over the three axes: the bins of all axes are filled in one pass over the range
+        struct Bins {
+            Box bb[3][kBins];
+            uint32_t cnt[3][kBins];
+        };
+        Bins one;  // (the common case, a range on one thread, allocates nothing)
+        std::vector<Bins> many;
+        if (pieces > 1u) many.resize(pieces);
+        Bins* pbins = pieces > 1u ? many.data() : &one;
+        float scale3[3];
+        for (int a = 0; a < 3; ++a) scale3[a] = ext[a] > 0.f ? (float)kBins / ext[a] : 0.f;
+        in_pieces(b, e, pieces, [&](unsigned k, uint32_t lo, uint32_t hi) {
+            Bins& B = pbins[k];
+            for (int a = 0; a < 3; ++a)
+                for (int j = 0; j < kBins; ++j) { B.bb[a][j].reset(); B.cnt[a][j] = 0; }
+            for (uint32_t i = lo; i < hi; ++i) {
+                for (int a = 0; a < 3; ++a) {
+                    if (!(ext[a] > 0.f)) continue;
+                    int j = (int)((centroid(prims[i], a) - cbox.mn[a]) * scale3[a]);
+                    j = std::min(std::max(j, 0), kBins - 1);
+                    B.bb[a][j].grow(prims[i].bmin, prims[i].bmax);
+                    B.cnt[a][j]++;
+                }
+            }
+        });
         for (int a = 0; a < 3; ++a) {
             if (!(ext[a] > 0.f)) continue;
             Box bb[kBins];
             uint32_t cnt[kBins];
             for (int k = 0; k < kBins; ++k) { bb[k].reset(); cnt[k] = 0; }
-            const float scale = (float)kBins / ext[a];
-            for (uint32_t i = b; i < e; ++i) {
-                int k = (int)((centroid(prims[i], a) - cbox.mn[a]) * scale);
-                k = std::min(std::max(k, 0), kBins - 1);
-                bb[k].grow(prims[i].bmin, prims[i].bmax);
-                cnt[k]++;
-            }
+            for (unsigned q = 0; q < pieces; ++q)
+                for (int k = 0; k < kBins; ++k) {
+                    if (pbins[q].cnt[a][k]) bb[k].grow(pbins[q].bb[a][k]);
+                    cnt[k] += pbins[q].cnt[a][k];
+                }
             float right_area[kBins];
             uint32_t right_cnt[kBins];
             Box acc;
@@ -223,6 +289,7 @@ BuildResult build_bvh(std::vector<BuildPrim>& prims, std::vector<BvhNode>& nodes
     bld.local.resize(std::max<uint32_t>(n, 1u) + 1u);
     std::memset(bld.local.data(), 0, bld.local.size() * sizeof(BvhNode));
     bld.spare_threads.store(threads > 1 ? (int)threads - 1 : 0);
+    bld.total_threads = threads > 0 ? threads : 1u;
 
     const int32_t ref_empty = (int32_t)(REF_LEAF | (5u << 28));  // kind 5: empty child, skipped by traversal
     auto set_empty_box = [](float* mn, float* mx) {
