@@ -14,7 +14,7 @@ def same_bits(a, b):
     return a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("name", ["suzanne", "mixed", "instanced", "cornell", "synthetic"])
+@pytest.mark.parametrize("name", ["suzanne", "mixed", "instanced", "instanced_tris", "cornell", "synthetic"])
 def test_device_built_scenes_match_the_oracle_and_the_host_build(rrt, oracle, monkeypatch, name):
     monkeypatch.setenv("RRT_DEVICE_BUILD_MIN", "2")  # these scenes are small: send every BVH to the GPU builder
     scene = helpers.SCENES[name](rrt)

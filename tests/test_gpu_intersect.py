@@ -49,7 +49,7 @@ def test_golden_vectors(rrt, renderer_cache, golden_dir, name):
         helpers.assert_hits_match(r.intersect(g[f"{kind}_rays"]), g[f"{kind}_hits"])
 
 
-def test_unrolled_and_two_level_instances_give_the_same_hits(rrt, oracle, renderer_cache):
+def test_unrolled_and_two_level_instances_give_the_same_hits(rrt, oracle, renderer_cache, monkeypatch):
     """Triangle-only instanced meshes are written out as world-space copies of their tree inside the top-level BVH by
     default; RRT_CFG_NO_UNROLL keeps the two-level walk of the reference (src/geometry/transform.rs:22-31,99-130).  Both
     run the same primitive tests on the same operands: records identical bit for bit, and equal to the oracle's."""
@@ -64,6 +64,12 @@ def test_unrolled_and_two_level_instances_give_the_same_hits(rrt, oracle, render
         assert np.array_equal(a, b), kind
         helpers.assert_hits_match(a, o.intersect(rays))
     two.close()
+    # the plain one-lane-per-ray kernel (an experiment knob) walks the unrolled tree as well
+    rays = helpers.primary_rays(o, 160, 90, 2048, seed=9)
+    want = r.intersect(rays)
+    monkeypatch.setenv("RRT_INTERSECT_STATIC", "1")
+    assert np.array_equal(r.intersect(rays), want)
+    monkeypatch.delenv("RRT_INTERSECT_STATIC")
     # a mesh that holds anything but triangles keeps the two-level form
     r2, _ = get(rrt, renderer_cache, "instanced")
     assert r2.info().unrolled_instances == 0
