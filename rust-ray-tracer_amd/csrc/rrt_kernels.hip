@@ -500,6 +500,15 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_STREAM_W
     lds_int* lim = (lds_int*)s_stack + K * RENDER_BLOCK;
     int deep[K > 0 ? STACK_DEPTH - K : 1];
     lds_float* wray = INST ? (lds_float*)(s_wray + threadIdx.x) : nullptr;
+    // unrolled scenes: the instance transforms in LDS, as in the render kernel
+    __shared__ vec4f s_xf[MODE == MODE_UNROLLED ? 2 * XF_LDS_SLOTS : 1];
+    const lds_float4* xf_lds = nullptr;
+    if (MODE == MODE_UNROLLED && S.inst_count + 1u <= (uint32_t)XF_LDS_SLOTS) {
+        const vec4f* src = reinterpret_cast<const vec4f*>(S.insts - 1);
+        for (uint32_t i = threadIdx.x; i < 2u * (S.inst_count + 1u); i += RENDER_BLOCK) s_xf[i] = src[(i >> 1) * 4u + (i & 1u)];
+        __syncthreads();
+        xf_lds = (const lds_float4*)s_xf;
+    }
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t mine = 0xFFFFFFFFu;  // index of the ray this lane is walking (or has walked and not yet written)
     V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_STREAM_W
         const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0 || (INST && trav_due(T.cur))));
         const uint32_t share = (n_walk * node_share_64ths) >> 6;
         if (n_desc >= share) trav_nodes<MODE, COUNT, K, 3>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
-        if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, tmin, RENDER_BLOCK, T, cnt, lim, deep, wray);
+        if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, tmin, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
     }
     if (COUNT) {
         const unsigned long long nn = wave_sum((unsigned long long)cnt.nodes);
