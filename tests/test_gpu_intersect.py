@@ -264,6 +264,38 @@ def test_random_soups_with_hostile_coordinates(rrt, oracle, monkeypatch, device_
         r.close()
 
 
+def test_unrolled_scene_with_more_instances_than_the_kernels_keep_in_lds(rrt, oracle):
+    """The kernels keep the transforms of up to 127 instances in LDS and read the table from device memory beyond that:
+    150 instances of a small mesh, hits and image against the two-level form and the oracle."""
+    from rust_ray_tracer_amd import scenes
+
+    g = np.random.default_rng(5)
+    s = rrt.Scene()
+    grey = s.add_material(rrt.Lambertian(0.6, 0.6, 0.6))
+    light = s.add_material(rrt.DiffuseLight(200.0, 200.0, 200.0))
+    mesh = s.new_mesh()
+    s.add_triangles(scenes.blob_mesh(5, 6, 0.35, 0.3, seed=2), grey, mesh=mesh)
+    mi = s.finish_mesh(mesh)
+    for k in range(150):
+        s.add_instance(mi, angle_deg=float(g.uniform(0, 360)), offset=(float((k % 15) - 7) * 0.9, float(g.uniform(-0.3, 0.3)), float((k // 15) - 5) * 0.9))
+    s.add_sphere((0.0, 6.0, 0.0), 0.5, light)
+    s.add_sphere_light((0.0, 6.0, 0.0), 0.5)
+    s.camera = rrt.Camera(16.0 / 9.0, 45.0, scenes.look_at_c2w((0.0, 5.0, 9.0), (0.0, 0.0, 0.0)))
+    s.background = (0.05, 0.05, 0.06)
+    a, b = rrt.Renderer(seed=3), rrt.Renderer(seed=3, unroll_instances=False)
+    assert a.upload(s).unrolled_instances == 150 and b.upload(s).unrolled_instances == 0
+    o = oracle.OracleScene(s)
+    for kind, rays in helpers.ray_suite(s, o, n=2048, seed=8).items():
+        ga, gb = a.intersect(rays), b.intersect(rays)
+        assert np.array_equal(ga, gb), kind
+        helpers.assert_hits_match(ga, o.intersect(rays))
+    ia, sa = a.render(128, 72, 4)
+    ib, sb = b.render(128, 72, 4)
+    assert sa.rays == sb.rays and np.array_equal(ia, ib)
+    a.close()
+    b.close()
+
+
 def test_unrolled_instances_with_hostile_coordinates(rrt, oracle):
     """Unrolled instances put world-space boxes around triangles that are tested in object space, with the ray moved
     there in f32: the boxes' pad has to cover the rounding of that move.  Small meshes far from the origin, far from
