@@ -166,26 +166,40 @@ __device__ __forceinline__ V3 onb_local(const Onb& o, V3 a) { return (a.x * o.u 
 // ---------------------------------------------------------------------------------------------
 struct Best {
     float t;        // closest t so far (starts at the query's t_max)
-    uint32_t id;    // primitive id of the closest hit (0xFFFFFFFF: none)
     float u, v;
-    uint32_t what;  // kind << 28 | record index
+    uint32_t what;  // kind << 28 | record index of the closest hit; WHAT_NONE: none yet
     int32_t inst;   // instance record the hit lies in, -1 for top-level primitives
 };
-
-__device__ __forceinline__ bool better(float t, uint32_t id, const Best& b) { return t < b.t || id < b.id; }
+static constexpr uint32_t WHAT_NONE = 0xFFFFFFFFu;
 
 // Ids of an instance's primitives are id_base + local id (top-level primitives: the local id).  The base is looked up in
-// the instance record when a hit is accepted, which is rare against the number of tests; carried in a register through
+// the instance record when it is needed, which is rare against the number of tests; carried in a register through
 // the walk it would cost the instanced kernels one of the registers their occupancy depends on.
 __device__ __forceinline__ uint32_t instance_id_base(const InstRec* __restrict__ insts, int32_t inst) {
     return inst >= 0 ? insts[inst].id_base : 0u;
 }
 
+// Primitive id of a recorded hit.  The closest hit is the minimum of (t, id), but the id only decides between two hits
+// at exactly the same t, so the walk does not carry it: it is read from the records when two candidates tie, and when a
+// caller wants it reported.
+__device__ __forceinline__ uint32_t prim_id_of(const SceneDev& S, uint32_t what, int32_t inst) {
+    if (what == WHAT_NONE) return 0xFFFFFFFFu;
+    const uint32_t kind = what >> 28, idx = what & REF_OFFSET_MASK;
+    const uint32_t local = kind == KIND_TRI ? S.tris[idx].id : (kind == KIND_SPHERE ? S.spheres[idx].id : S.rects[idx].id);
+    return instance_id_base(S.insts, inst) + local;
+}
+
+// A candidate at t (already known to lie in [tmin, best.t]) with local id `lid` in instance `inst` replaces the closest
+// hit so far if it is nearer, or as near with the lower id.
+__device__ __forceinline__ bool better(const SceneDev& S, float t, uint32_t lid, int32_t inst, const Best& b) {
+    if (t < b.t) return true;
+    return instance_id_base(S.insts, inst) + lid < prim_id_of(S, b.what, b.inst);  // t == b.t: rare
+}
+
 // reference src/geometry/triangle.rs:38-69
-__device__ __forceinline__ void test_triangle(const TriRec* __restrict__ tris, uint32_t idx, V3 o, V3 d, float tmin,
-                                              const InstRec* __restrict__ insts, int32_t inst, Best& best) {
+__device__ __forceinline__ void test_triangle(const SceneDev& S, uint32_t idx, V3 o, V3 d, float tmin, int32_t inst, Best& best) {
     // 48-byte records at a 32-bit byte offset (two shifts) from the uniform base
-    const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tris) + ((idx << 5) + (idx << 4)));
+    const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tris) + ((idx << 5) + (idx << 4)));
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q1.x, q1.y, q1.z), e2 = v3(q2.x, q2.y, q2.z);
     const V3 pvec = cross(d, e2);
@@ -200,9 +214,8 @@ __device__ __forceinline__ void test_triangle(const TriRec* __restrict__ tris, u
             if (v >= 0.0f && v < 1.0f - u) {
                 const float t = dot(e2, qvec) * inv_det;
                 if (t >= tmin && t <= best.t) {
-                    const uint32_t id = instance_id_base(insts, inst) + __float_as_uint(q0.w);
-                    if (better(t, id, best)) {
-                        best.t = t; best.id = id; best.u = u; best.v = v;
+                    if (better(S, t, __float_as_uint(q0.w), inst, best)) {
+                        best.t = t; best.u = u; best.v = v;
                         best.what = (KIND_TRI << 28) | idx; best.inst = inst;
                     }
                 }
@@ -228,15 +241,12 @@ __device__ __forceinline__ float sphere_root(V3 c, float radius, V3 o, V3 d, flo
     return __uint_as_float(0x7fc00000U);
 }
 
-__device__ __forceinline__ void test_sphere(const SphereRec* __restrict__ spheres, uint32_t idx, V3 o, V3 d, float tmin,
-                                            const InstRec* __restrict__ insts, int32_t inst, Best& best) {
-    const float4 q0 = *reinterpret_cast<const float4*>(&spheres[idx].c[0]);
-    const uint32_t lid = spheres[idx].id;
+__device__ __forceinline__ void test_sphere(const SceneDev& S, uint32_t idx, V3 o, V3 d, float tmin, int32_t inst, Best& best) {
+    const float4 q0 = *reinterpret_cast<const float4*>(&S.spheres[idx].c[0]);
     const float t = sphere_root(v3(q0.x, q0.y, q0.z), q0.w, o, d, tmin, best.t);
     if (t == t) {
-        const uint32_t id = instance_id_base(insts, inst) + lid;
-        if (better(t, id, best)) {
-            best.t = t; best.id = id; best.u = 0.0f; best.v = 0.0f;
+        if (better(S, t, S.spheres[idx].id, inst, best)) {
+            best.t = t; best.u = 0.0f; best.v = 0.0f;
             best.what = (KIND_SPHERE << 28) | idx; best.inst = inst;
         }
     }
@@ -265,15 +275,13 @@ __device__ __forceinline__ bool rect_hit(float a0, float a1, float b0, float b1,
     }
     return false;
 }
-__device__ __forceinline__ void test_rect(const RectRec* __restrict__ rects, uint32_t idx, V3 o, V3 d, float tmin,
-                                          const InstRec* __restrict__ insts, int32_t inst, Best& best) {
-    const float4 q0 = *reinterpret_cast<const float4*>(&rects[idx].a0);
-    const float4 q1 = *reinterpret_cast<const float4*>(&rects[idx].k);
+__device__ __forceinline__ void test_rect(const SceneDev& S, uint32_t idx, V3 o, V3 d, float tmin, int32_t inst, Best& best) {
+    const float4 q0 = *reinterpret_cast<const float4*>(&S.rects[idx].a0);
+    const float4 q1 = *reinterpret_cast<const float4*>(&S.rects[idx].k);
     float t, u, v;
     if (rect_hit(q0.x, q0.y, q0.z, q0.w, q1.x, __float_as_uint(q1.y) & 3u, o, d, tmin, best.t, t, u, v)) {
-        const uint32_t id = instance_id_base(insts, inst) + __float_as_uint(q1.z);
-        if (better(t, id, best)) {
-            best.t = t; best.id = id; best.u = u; best.v = v;
+        if (better(S, t, __float_as_uint(q1.z), inst, best)) {
+            best.t = t; best.u = u; best.v = v;
             best.what = (KIND_RECT << 28) | idx; best.inst = inst;
         }
     }
@@ -402,7 +410,7 @@ __device__ __forceinline__ void slab_pair(uint32_t w, uint32_t rot, float a, flo
 
 template <int MODE>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, lds_int* stack, int stride, Trav& T) {
-    T.best.t = tmax; T.best.id = 0xFFFFFFFFu; T.best.u = 0.f; T.best.v = 0.f; T.best.what = 0u; T.best.inst = -1;
+    T.best.t = tmax; T.best.u = 0.f; T.best.v = 0.f; T.best.what = WHAT_NONE; T.best.inst = -1;
     trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
     T.cur_inst = -1;
     stack[0] = REF_DONE;
@@ -575,7 +583,6 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
     const uint32_t kind = (ref >> 28) & 7u;
     uint32_t first = ref & REF_OFFSET_MASK;
     V3 ro = o, rd = d;  // the ray in the space being walked
-    const InstRec* insts = MODE != MODE_FLAT ? S.insts : nullptr;
     int32_t tri_inst = T.cur_inst;  // instance a triangle of this leaf belongs to
     uint32_t first_mask = REF_OFFSET_MASK;
     if (MODE == MODE_UNROLLED) {
@@ -608,7 +615,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
     // its stack top is in LDS.  The step then ends without a branch: the entry below the top is read in any case and
     // becomes current, and the top moves down, only if the leaf has no triangle left.
     if (__builtin_expect(__ballot(kind != KIND_TRI || (K > 0 && T.top - stride >= lim)) == 0ull, 1)) {
-        test_triangle(S.tris, first, ro, rd, tmin, insts, tri_inst, T.best);
+        test_triangle(S, first, ro, rd, tmin, tri_inst, T.best);
         if (COUNT) {
             cnt.prims++;
             if (first_active_lane()) cnt.wave_prims++;
@@ -621,7 +628,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
         bool more = ((r >> 25) & 7u) != 0u;
         if (PAIR && more) {
             r += 1u - (1u << 25);  // next record, one triangle fewer
-            test_triangle(S.tris, r & first_mask, ro, rd, tmin, insts, tri_inst, T.best);
+            test_triangle(S, r & first_mask, ro, rd, tmin, tri_inst, T.best);
             if (COUNT) {
                 cnt.prims++;
                 if (first_active_lane()) cnt.wave_prims++;
@@ -635,7 +642,7 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
         return;
     }
     if (kind == KIND_TRI) {
-        test_triangle(S.tris, first, ro, rd, tmin, insts, tri_inst, T.best);
+        test_triangle(S, first, ro, rd, tmin, tri_inst, T.best);
         if (COUNT) {
             cnt.prims++;
             if (first_active_lane()) cnt.wave_prims++;
@@ -645,10 +652,10 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
             return;
         }
     } else if (kind == KIND_SPHERE) {
-        test_sphere(S.spheres, first, ro, rd, tmin, insts, T.cur_inst, T.best);
+        test_sphere(S, first, ro, rd, tmin, T.cur_inst, T.best);
         if (COUNT) cnt.prims++;
     } else if (kind == KIND_RECT) {
-        test_rect(S.rects, first, ro, rd, tmin, insts, T.cur_inst, T.best);
+        test_rect(S, first, ro, rd, tmin, T.cur_inst, T.best);
         if (COUNT) cnt.prims++;
     } else if (INST && kind == KIND_INST) {
         const InstRec in = S.insts[first];

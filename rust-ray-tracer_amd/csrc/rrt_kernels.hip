@@ -201,7 +201,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                     // background; neither scatters), so the sample's radiance is this one term: no sum is carried
                     // from bounce to bounce.
                     V3 radiance = v3(0.f, 0.f, 0.f);
-                    if (T.best.id == 0xFFFFFFFFu) {
+                    if (T.best.what == WHAT_NONE) {
                         radiance = radiance + mulv(beta, bg);  // ray.rs:126
                         alive = false;
                     } else {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 if (shade_now) {
                     n_rays++;
                     if (COUNT && first_active_lane()) cnt.wave_shade++;
-                    if (T.best.id == 0xFFFFFFFFu) {
+                    if (T.best.what == WHAT_NONE) {
                         radiance = radiance + mulv(beta, bg);  // ray.rs:126
                     } else {
                         const Surface sf = surface_at(S, T.best, o, d);
@@ -420,10 +420,10 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
 // (src/geometry/sphere.rs:34-40), including its far-root call with the un-normalised p.
 __device__ __forceinline__ rrt_hit hit_record(const SceneDev& S, const Best& best, V3 o, V3 d) {
     rrt_hit h;
-    if (best.id == 0xFFFFFFFFu) {
+    if (best.what == WHAT_NONE) {
         h.prim_id = -1; h.t = __builtin_inff(); h.u = 0.f; h.v = 0.f;
     } else {
-        h.prim_id = (int32_t)best.id; h.t = best.t; h.u = best.u; h.v = best.v;
+        h.prim_id = (int32_t)prim_id_of(S, best.what, best.inst); h.t = best.t; h.u = best.u; h.v = best.v;
         if ((best.what >> 28) == KIND_SPHERE) {
             const uint32_t idx = best.what & REF_OFFSET_MASK;
             V3 ro = o, rd = d;
