@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -161,6 +162,16 @@ __global__ void k_topology(const unsigned long long* __restrict__ keys, int n, T
     if (i == 0) parent[0] = -1;
 }
 
+__device__ __forceinline__ uint32_t count_of(const Topo& t) { return (uint32_t)(t.last - t.first + 1); }
+
+// A radix subtree that the traversal sees as one triangle leaf.
+__device__ __forceinline__ bool collapsed_leaf(const Topo& t, const uint32_t* __restrict__ tri_prefix, uint32_t leaf_tris) {
+    // (both loads always: with the second one behind the first comparison, hipcc 7.2 reuses the register of a value
+    // loaded earlier -- the child's depth in view_child -- and sets it to zero on both sides of the branch)
+    const uint32_t cnt = count_of(t), tris = tri_prefix[t.last + 1] - tri_prefix[t.first];
+    return (cnt <= leaf_tris) & (tris == cnt);
+}
+
 struct ChildView {
     bool ready;
     float mn[3], mx[3];
@@ -186,24 +197,31 @@ __device__ __forceinline__ ChildView view_child(int c, const Topo* __restrict__ 
     v.ready = s.done != 0u && s.done < launch;  // finished by an EARLIER launch
     for (int a = 0; a < 3; ++a) { v.mn[a] = s.mn[a]; v.mx[a] = s.mx[a]; }
     const Topo t = topo[c];
-    const uint32_t cnt = (uint32_t)(t.last - t.first + 1);
-    if (cnt <= leaf_tris && tri_prefix[t.last + 1] - tri_prefix[t.first] == cnt) {
-        v.ref = (int32_t)make_leaf_ref(KIND_TRI, tri_base + tri_prefix[t.first], cnt);
-        v.depth = 0u;
-    } else {
-        v.ref = (int32_t)(node_base + (uint32_t)c);
-        v.depth = s.depth;
-    }
+    const uint32_t first_tri = tri_prefix[t.first];
+    const bool collapsed = collapsed_leaf(t, tri_prefix, leaf_tris);
+    v.ref = collapsed ? (int32_t)make_leaf_ref(KIND_TRI, tri_base + first_tri, count_of(t)) : (int32_t)(node_base + (uint32_t)c);
+    v.depth = collapsed ? 0u : s.depth;
     return v;
 }
 
-__global__ void k_refit(const Topo* __restrict__ topo, const LeafInfo* __restrict__ leaf, const uint32_t* __restrict__ tri_prefix,
-                        NodeState* __restrict__ st, QNode* __restrict__ nodes, uint32_t n, uint32_t launch, Grid g,
-                        uint32_t node_base, uint32_t tri_base, uint32_t leaf_tris) {
+// The radix nodes whose slots belong to k_cluster_sah (sah_size > 0): everything inside a subtree of at most sah_size
+// primitives that hangs below a larger node, and that subtree's root unless it is a collapsed leaf.
+__device__ __forceinline__ bool owned_by_cluster(int i, const Topo& t, const Topo* __restrict__ topo, const int* __restrict__ parent,
+                                                 const uint32_t* __restrict__ tri_prefix, uint32_t sah_size, uint32_t leaf_tris) {
+    if (sah_size == 0u || count_of(t) > sah_size) return false;
+    const int p = parent[i];
+    if (p >= 0 && count_of(topo[p]) <= sah_size) return true;
+    return !collapsed_leaf(t, tri_prefix, leaf_tris);
+}
+
+__global__ void k_refit(const Topo* __restrict__ topo, const int* __restrict__ parent, const LeafInfo* __restrict__ leaf,
+                        const uint32_t* __restrict__ tri_prefix, NodeState* __restrict__ st, QNode* __restrict__ nodes, uint32_t n,
+                        uint32_t launch, Grid g, uint32_t node_base, uint32_t tri_base, uint32_t leaf_tris, uint32_t sah_size) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n - 1u) return;
     if (st[i].done != 0u) return;
     const Topo t = topo[i];
+    if (owned_by_cluster((int)i, t, topo, parent, tri_prefix, sah_size, leaf_tris)) return;
     const ChildView l = view_child(t.left, topo, leaf, tri_prefix, st, launch, node_base, tri_base, leaf_tris);
     if (!l.ready) return;
     const ChildView r = view_child(t.right, topo, leaf, tri_prefix, st, launch, node_base, tri_base, leaf_tris);
@@ -285,6 +303,264 @@ __global__ void k_permute_tris(const LeafInfo* __restrict__ leaf, const uint32_t
     const float4* s = reinterpret_cast<const float4*>(src + l.index);
     float4* d = reinterpret_cast<float4*>(dst + to);
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
+// ---- subtrees below the cut, rebuilt on the GPU with the surface-area heuristic -----------------------------------
+//
+// One wavefront per subtree of at most 64 primitives, one primitive per lane.  The tree is built top-down, all segments
+// of one level at once: a segment is a run of lanes [lo, hi); every level sorts the lanes by (segment, centroid) along
+// each axis with one bitonic network over the wavefront, forms the boxes left and right of every split position with
+// segmented scans, and takes the cheapest split of the three axes (full sweep, the host builder's cost: area x count).
+// Triangle segments end as leaves by the host builder's rule (count <= node cost + split cost / area).  The subtree's
+// nodes go into the slots of the radix nodes they replace: a radix subtree over sorted positions [f, l] owns the
+// slots f..l-1 (root at f) or f+1..l (root at l), one per gap between neighbouring positions, and the root keeps its
+// slot, so whatever refers to the subtree stays valid.
+constexpr int CL_MAX = 64;          // primitives per rebuilt subtree
+constexpr int CL_WAVES = 4;         // wavefronts per workgroup
+constexpr uint32_t CL_LEVELS = 10;  // node levels a rebuilt subtree may have (a balanced tree over 64 primitives needs 6)
+
+__global__ void k_cluster_roots(const Topo* __restrict__ topo, const int* __restrict__ parent, const uint32_t* __restrict__ tri_prefix,
+                                uint32_t n, uint32_t sah_size, uint32_t leaf_tris, uint32_t* __restrict__ roots, uint32_t* __restrict__ count) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n - 1u) return;
+    const Topo t = topo[i];
+    if (count_of(t) > sah_size) return;
+    const int p = parent[i];
+    if (p < 0 || count_of(topo[p]) <= sah_size) return;
+    if (collapsed_leaf(t, tri_prefix, leaf_tris)) return;
+    roots[atomicAdd(count, 1u)] = i;  // the order does not matter: subtrees are independent of each other
+}
+
+__device__ __forceinline__ uint32_t orderable(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+__device__ __forceinline__ float half_area(const float* mn, const float* mx) {
+    const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__device__ __forceinline__ uint32_t ceil_log2_dev(uint32_t x) { return x <= 1u ? 0u : 32u - (uint32_t)__clz((int)(x - 1u)); }
+
+// Ascending sort of 64 distinct keys, one per lane (bitonic network).
+__device__ __forceinline__ unsigned long long wave_sort(unsigned long long key, int lane) {
+    for (int k2 = 2; k2 <= 64; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(key, j, 64);
+            const bool take_min = ((lane & j) == 0) == ((lane & k2) == 0);
+            const bool swap = take_min ? other < key : other > key;
+            key = swap ? other : key;
+        }
+    return key;
+}
+
+// Lanes sorted by (segment, c) -- src: the lane whose primitive comes to this position -- and, for every position r of
+// a segment [lo, hi), the box of positions lo..r (lmn, lmx) and of positions r+1..hi-1 (rmn, rmx; garbage at r = hi-1).
+__device__ __forceinline__ void sweep(int lane, int lo, int hi, float c, const float* mn, const float* mx, int& src, float* lmn,
+                                      float* lmx, float* rmn, float* rmx) {
+    unsigned long long key = ((unsigned long long)(uint32_t)lo << 38) | ((unsigned long long)orderable(c) << 6) | (unsigned long long)lane;
+    key = wave_sort(key, lane);
+    src = (int)(key & 63ull);
+    float smn[3], smx[3];
+    for (int a = 0; a < 3; ++a) {
+        lmn[a] = smn[a] = __shfl(mn[a], src, 64);
+        lmx[a] = smx[a] = __shfl(mx[a], src, 64);
+    }
+    for (int d = 1; d < 64; d <<= 1) {
+        const bool in = lane - d >= lo;
+        for (int a = 0; a < 3; ++a) {
+            const float o0 = __shfl_up(lmn[a], d, 64), o1 = __shfl_up(lmx[a], d, 64);
+            if (in) { lmn[a] = fminf(lmn[a], o0); lmx[a] = fmaxf(lmx[a], o1); }
+        }
+    }
+    for (int d = 1; d < 64; d <<= 1) {
+        const bool in = lane + d < hi;
+        for (int a = 0; a < 3; ++a) {
+            const float o0 = __shfl_down(smn[a], d, 64), o1 = __shfl_down(smx[a], d, 64);
+            if (in) { smn[a] = fminf(smn[a], o0); smx[a] = fmaxf(smx[a], o1); }
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        rmn[a] = __shfl_down(smn[a], 1, 64);
+        rmx[a] = __shfl_down(smx[a], 1, 64);
+    }
+}
+
+__global__ __launch_bounds__(CL_MAX * CL_WAVES) void k_cluster_sah(
+    const uint32_t* __restrict__ roots, const uint32_t* __restrict__ root_count, const Topo* __restrict__ topo, LeafInfo* __restrict__ leaf,
+    uint32_t* __restrict__ tri_prefix, NodeState* __restrict__ st, QNode* __restrict__ nodes, Grid g, uint32_t node_base, uint32_t tri_base,
+    uint32_t leaf_tris, float node_cost, uint32_t* __restrict__ failed) {
+    __shared__ QNode s_nodes[CL_WAVES][CL_MAX];
+    const int lane = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
+    const uint32_t ci = blockIdx.x * CL_WAVES + (uint32_t)w;
+    if (ci >= *root_count) return;  // the whole wavefront leaves; the kernel has no workgroup barrier
+    const uint32_t c = roots[ci];
+    const Topo t = topo[c];
+    const int k = t.last - t.first + 1;
+    if (k < 2 || k > CL_MAX) {
+        if (lane == 0) *failed = 1u;
+        return;
+    }
+    const bool valid = lane < k;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    uint32_t kind = 0xFFFFFFFFu, index = 0u;
+    if (valid) {
+        const LeafInfo l = leaf[t.first + lane];
+        for (int a = 0; a < 3; ++a) { mn[a] = l.mn[a]; mx[a] = l.mx[a]; }
+        kind = l.kind;
+        index = l.index;
+    }
+    const uint32_t tri0 = tri_prefix[t.first];
+    int lo = valid ? 0 : lane, hi = valid ? k : lane + 1;
+    bool done = !valid;
+    int parent_gap = -1, side = 0, root_gap = 0;
+    uint32_t depth_here = 0u;
+    unsigned long long used = 0ull;
+    float cmn[3] = {0.f, 0.f, 0.f}, cmx[3] = {0.f, 0.f, 0.f};  // the subtree's box
+
+    for (uint32_t level = 0; level <= CL_LEVELS; ++level) {
+        const unsigned long long tri_mask = __ballot(kind == KIND_TRI);
+        const unsigned long long seg_mask = (hi >= 64 ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << lo) - 1ull);
+        const int cnt = hi - lo;
+        const bool all_tri = (tri_mask & seg_mask) == seg_mask;
+        const bool open = !done;
+        bool eval = open && cnt > 1;
+        if (__ballot(open) == 0ull) break;
+        const uint32_t rem = CL_LEVELS - level;  // node levels this segment's subtree may still use
+        bool make_leaf = open && cnt == 1;
+        if (eval && rem == 0u) {
+            // cannot happen (a split is only taken if both sides still fit a balanced tree); kept so that a mistake
+            // ends in an error and not in a tree the traversal cannot walk
+            if (lane == lo) *failed = 1u;
+            make_leaf = true;
+            eval = false;
+        }
+
+        // --- cheapest split of every open segment: full sweep along the three axes
+        unsigned long long best = ~0ull;
+        float ext[3] = {0.f, 0.f, 0.f}, parent_area = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            const float cen = eval ? 0.5f * (mn[a] + mx[a]) : 0.f;
+            int src;
+            float lmn[3], lmx[3], rmn[3], rmx[3];
+            sweep(lane, lo, hi, cen, mn, mx, src, lmn, lmx, rmn, rmx);
+            const float sorted_c = __shfl(cen, src, 64);
+            ext[a] = __shfl(sorted_c, hi - 1, 64) - __shfl(sorted_c, lo, 64);
+            if (a == 0) {
+                parent_area = __shfl(half_area(lmn, lmx), hi - 1, 64);
+                if (level == 0u)
+                    for (int b = 0; b < 3; ++b) { cmn[b] = __shfl(lmn[b], k - 1, 64); cmx[b] = __shfl(lmx[b], k - 1, 64); }
+            }
+            float cost = half_area(lmn, lmx) * (float)(lane - lo + 1) + half_area(rmn, rmx) * (float)(hi - 1 - lane);
+            if (!eval || lane >= hi - 1 || !(cost >= 0.f) || !(cost < 3.0e38f)) cost = 3.4e38f;
+            const unsigned long long ck = ((unsigned long long)__float_as_uint(cost) << 8) | ((unsigned long long)a << 6) | (unsigned long long)lane;
+            best = ck < best ? ck : best;
+        }
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = __shfl_up(best, d, 64);
+            if (lane - d >= lo && o < best) best = o;
+        }
+        best = __shfl(best, hi - 1, 64);
+        const float best_cost = __uint_as_float((uint32_t)(best >> 8));
+        int axis = (int)((best >> 6) & 3ull), split = (int)(best & 63ull);
+        bool have = eval && best_cost < 3.0e38f && axis < 3 && split >= lo && split < hi - 1;
+        if (eval && level > 0u && all_tri && (uint32_t)cnt <= leaf_tris) {
+            const float split_cost = (have && parent_area > 0.f) ? node_cost + best_cost / parent_area : 3.4e38f;
+            if ((float)cnt <= split_cost) { make_leaf = true; eval = false; }
+        }
+        if (eval) {
+            if (have && (ceil_log2_dev((uint32_t)(split - lo + 1)) + 1u > rem || ceil_log2_dev((uint32_t)(hi - 1 - split)) + 1u > rem)) have = false;
+            if (!have) {  // median split along the widest axis (by position when all centroids coincide)
+                axis = 0;
+                if (ext[1] > ext[axis]) axis = 1;
+                if (ext[2] > ext[axis]) axis = 2;
+                split = lo + cnt / 2 - 1;
+            }
+        }
+
+        // --- the lanes of a splitting segment take the order of its axis; everything else stays where it is
+        {
+            const float cen = eval ? 0.5f * (mn[axis] + mx[axis]) : 0.f;
+            int src;
+            float lmn[3], lmx[3], rmn[3], rmx[3];
+            sweep(lane, lo, hi, cen, mn, mx, src, lmn, lmx, rmn, rmx);
+            for (int a = 0; a < 3; ++a) { mn[a] = __shfl(mn[a], src, 64); mx[a] = __shfl(mx[a], src, 64); }
+            kind = (uint32_t)__shfl((int)kind, src, 64);
+            index = (uint32_t)__shfl((int)index, src, 64);
+            if (eval && lane == split) {
+                QNode q;
+                q.left = q.right = REF_DONE;
+                quantize_box(g, lmn, lmx, q.lbox);
+                quantize_box(g, rmn, rmx, q.rbox);
+                s_nodes[w][split] = q;
+            }
+        }
+        used |= __ballot(eval && lane == split);
+        if (level == 0u) root_gap = __shfl(split, 0, 64);
+
+        // --- what this segment is goes into its parent's node
+        if ((eval || make_leaf) && lane == lo && parent_gap >= 0) {
+            int32_t ref = split;  // the gap of the node; turned into a reference when the nodes are written out
+            if (make_leaf) {  // (the primitives below lo belong to other segments: their number of triangles is final)
+                ref = kind == KIND_TRI ? (int32_t)make_leaf_ref(KIND_TRI, tri_base + tri0 + (uint32_t)__popcll(tri_mask & ((1ull << lo) - 1ull)), (uint32_t)cnt)
+                                       : (int32_t)make_leaf_ref(kind, index, 1u);
+            }
+            if (side == 0) s_nodes[w][parent_gap].left = ref;
+            else s_nodes[w][parent_gap].right = ref;
+        }
+        if (make_leaf) {
+            done = true;
+            depth_here = level;
+        }
+        if (eval) {
+            parent_gap = split;
+            if (lane <= split) { hi = split + 1; side = 0; }
+            else { lo = split + 1; side = 1; }
+        }
+    }
+    if (__ballot(!done) != 0ull) {
+        if (lane == 0) *failed = 1u;
+        return;
+    }
+    uint32_t depth = valid ? depth_here : 0u;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)depth, d, 64);
+        depth = o > depth ? o : depth;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // --- results: the primitives in their new order, the nodes in their slots, the subtree's box for the levels above
+    if (valid) {
+        LeafInfo l;
+        for (int a = 0; a < 3; ++a) { l.mn[a] = mn[a]; l.mx[a] = mx[a]; }
+        l.kind = kind;
+        l.index = index;
+        leaf[t.first + lane] = l;
+    }
+    const unsigned long long tri_final = __ballot(kind == KIND_TRI);
+    if (valid) tri_prefix[t.first + lane] = tri0 + (uint32_t)__popcll(tri_final & ((1ull << lane) - 1ull));
+    const uint32_t slot0 = c == (uint32_t)t.first ? (uint32_t)t.first : (uint32_t)t.first + 1u;  // first of the k - 1 slots
+    const int root_at = c == (uint32_t)t.first ? 0 : k - 2;                                      // where the root's slot is among them
+    auto slot_of = [&](int gap) -> uint32_t {
+        const int m = gap == root_gap ? root_at : (gap == root_at ? root_gap : gap);
+        return node_base + slot0 + (uint32_t)m;
+    };
+    if (lane < k - 1 && ((used >> lane) & 1ull)) {
+        QNode q = s_nodes[w][lane];
+        if (q.left >= 0) q.left = device_ref((int32_t)slot_of(q.left));
+        if (q.right >= 0) q.right = device_ref((int32_t)slot_of(q.right));
+        nodes[slot_of(lane)] = q;
+    }
+    if (lane == 0) {
+        NodeState s;
+        for (int a = 0; a < 3; ++a) { s.mn[a] = cmn[a]; s.mx[a] = cmx[a]; }
+        s.depth = depth;
+        s.done = 1u;
+        st[c] = s;
+    }
 }
 
 struct Buffers {
@@ -380,6 +656,56 @@ static hipError_t rebuild_top(const uint32_t* d_upper, const Cluster* d_clusters
     return hipSuccess;
 }
 
+// RRT_LBVH_VERIFY=1: the finished tree is fetched and walked on the host before anything traverses it -- every node
+// slot inside the BVH's range and reached once, every triangle record in exactly one leaf, as many other leaves as
+// there are other primitives, no walk deeper than the depth reported.
+static hipError_t verify_tree(const QNode* d_nodes, uint32_t node_base, uint32_t n, uint32_t tri_base, uint32_t tri_count, uint32_t depth) {
+    std::vector<QNode> nodes(n - 1u);
+    LBVH_TRY(hipMemcpy(nodes.data(), d_nodes + node_base, nodes.size() * sizeof(QNode), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> seen_node(n - 1u, 0), seen_tri(tri_count, 0);
+    uint64_t others = 0;
+    struct Item { uint32_t node, level; };
+    std::vector<Item> todo{{0u, 1u}};
+    auto fail = [&](const char* what, uint32_t at) {
+        fprintf(stderr, "rrt: GPU-built BVH failed verification: %s (node %u of %u, depth reported %u)\n", what, at, n - 1u, depth);
+        if (n <= 64u)
+            for (uint32_t k = 0; k + 1u < n; ++k) fprintf(stderr, "  node %u: left %08x right %08x\n", k, (unsigned)nodes[k].left, (unsigned)nodes[k].right);
+        return hipErrorUnknown;
+    };
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.level > depth) return fail("deeper than reported", it.node);
+        if (seen_node[it.node]) return fail("node reached twice", it.node);
+        seen_node[it.node] = 1;
+        const int32_t child[2] = {nodes[it.node].left, nodes[it.node].right};
+        for (int k = 0; k < 2; ++k) {
+            if (child[k] >= 0) {
+                const uint32_t idx = (uint32_t)child[k] >> 5;
+                if (((uint32_t)child[k] & 31u) != 0u || idx < node_base || idx - node_base >= n - 1u) return fail("child outside the BVH's nodes", it.node);
+                todo.push_back({idx - node_base, it.level + 1u});
+                continue;
+            }
+            const uint32_t u = (uint32_t)child[k], kind = (u >> 28) & 7u, first = u & REF_OFFSET_MASK, cnt = ((u >> 25) & 7u) + 1u;
+            if (kind == KIND_TRI) {
+                if (first < tri_base || first - tri_base + cnt > tri_count) return fail("triangle leaf outside the BVH's records", it.node);
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    if (seen_tri[first - tri_base + j]) return fail("triangle in two leaves", it.node);
+                    seen_tri[first - tri_base + j] = 1;
+                }
+            } else if (kind == KIND_SPHERE || kind == KIND_RECT || kind == KIND_INST) {
+                ++others;
+            } else {
+                return fail("unexpected kind of child", it.node);
+            }
+        }
+    }
+    for (uint32_t j = 0; j < tri_count; ++j)
+        if (!seen_tri[j]) return fail("triangle in no leaf", j);
+    if (others != (uint64_t)n - tri_count) return fail("other primitives miscounted", (uint32_t)others);
+    return hipSuccess;
+}
+
 hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n_host, const Grid& grid, QNode* d_nodes, uint32_t node_base,
                       TriRec* d_tris, uint32_t tri_base, uint32_t tri_count, uint32_t max_depth, uint32_t cluster_size,
                       unsigned threads, LbvhResult* out, const RawTriRun* runs, size_t n_runs, float pad) {
@@ -431,6 +757,14 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n_host, const Grid& gri
     LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_tri, tri_prefix, (int)(n + 1u), (hipStream_t)0));
     unsigned char* temp;
     LBVH_TRY(B.alloc(&temp, sort_bytes > scan_bytes ? sort_bytes : scan_bytes));
+    // RRT_LBVH_SAH=0: keep the radix topology below the cut
+    bool sah = cut && cluster_size <= (uint32_t)CL_MAX;
+    if (const char* e = getenv("RRT_LBVH_SAH")) sah = sah && atoi(e) != 0;
+    uint32_t *cl_roots = nullptr, *cl_counters = nullptr;  // counters: [0] subtrees to rebuild, [1] set if one could not be rebuilt
+    if (sah) {
+        LBVH_TRY(B.alloc(&cl_roots, n));
+        LBVH_TRY(B.alloc(&cl_counters, 2));
+    }
     LBVH_TRY(hipEventCreate(&B.e0));
     LBVH_TRY(hipEventCreate(&B.e1));
 
@@ -467,8 +801,28 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n_host, const Grid& gri
     const uint32_t launches = max_depth + 7u;
     uint32_t leaf_tris = LBVH_LEAF_TRIS_DEFAULT;
     if (const char* e = getenv("RRT_LBVH_LEAF")) leaf_tris = (uint32_t)std::min(std::max(atoi(e), 1), (int)MAX_LEAF_TRIS);
-    for (uint32_t k = 1; k <= launches; ++k)
-        hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BLOCK), 0, s, topo, leaf, tri_prefix, st, d_nodes, n, k, grid, node_base, tri_base, leaf_tris);
+    uint32_t sah_failed = 0u;
+    if (sah) {
+        uint32_t sah_leaf = 4u;  // the host builder's bound (RRT_LEAF_TRIS there)
+        if (const char* e = getenv("RRT_LBVH_SAH_LEAF")) sah_leaf = (uint32_t)std::min(std::max(atoi(e), 1), (int)MAX_LEAF_TRIS);
+        float node_cost = 1.0f;
+        if (const char* e = getenv("RRT_SAH_TCOST")) node_cost = (float)atof(e);
+        LBVH_TRY(hipMemsetAsync(cl_counters, 0, 2 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_cluster_roots, dim3(blocks), dim3(BLOCK), 0, s, topo, parent, tri_prefix, n, cluster_size, leaf_tris, cl_roots, cl_counters);
+        LBVH_TRY(hipGetLastError());
+        uint32_t n_roots = 0;
+        LBVH_TRY(hipMemcpy(&n_roots, cl_counters, sizeof n_roots, hipMemcpyDeviceToHost));
+        if (n_roots > n - 1u) return hipErrorUnknown;
+        if (n_roots) {
+            hipLaunchKernelGGL(k_cluster_sah, dim3((n_roots + CL_WAVES - 1u) / CL_WAVES), dim3(CL_MAX * CL_WAVES), 0, s, cl_roots, cl_counters, topo,
+                               leaf, tri_prefix, st, d_nodes, grid, node_base, tri_base, sah_leaf, node_cost, cl_counters + 1);
+            LBVH_TRY(hipGetLastError());
+        }
+    }
+    // (the rebuilt subtrees carry launch number 1: the levels above them see them as finished from launch 2 on)
+    for (uint32_t k = 2; k <= launches + 1u; ++k)
+        hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(BLOCK), 0, s, topo, parent, leaf, tri_prefix, st, d_nodes, n, k, grid, node_base, tri_base,
+                           leaf_tris, sah ? cluster_size : 0u);
     if (tri_count) {
         LBVH_TRY(hipMemcpyAsync(tri_tmp, d_tris + tri_base, (size_t)tri_count * sizeof(TriRec), hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(k_permute_tris, dim3(blocks), dim3(BLOCK), 0, s, leaf, tri_prefix, n, tri_tmp, tri_count, d_tris + tri_base);
@@ -478,6 +832,8 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n_host, const Grid& gri
     NodeState root;
     LBVH_TRY(hipMemcpy(&root, st, sizeof root, hipMemcpyDeviceToHost));  // also waits for the stream
     LBVH_TRY(hipEventElapsedTime(&out->build_ms, B.e0, B.e1));
+    if (sah) LBVH_TRY(hipMemcpy(&sah_failed, cl_counters + 1, sizeof sah_failed, hipMemcpyDeviceToHost));
+    if (sah_failed != 0u) return hipSuccess;  // (depth 0: the caller builds this scene on the host)
     if (root.done != 0u && root.depth <= max_depth) out->depth = root.depth;
     if (cut) {
         // the radix tree above the cut need not fit the depth bound (nor be finished): only the clusters must
@@ -494,6 +850,9 @@ hipError_t lbvh_build(const BuildPrim* h_prims, uint32_t n_host, const Grid& gri
         }
         out->top_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    if (out->depth != 0u)
+        if (const char* e = getenv("RRT_LBVH_VERIFY"))
+            if (atoi(e) != 0) LBVH_TRY(verify_tree(d_nodes, node_base, n, tri_base, tri_count, out->depth));
     return hipSuccess;
 }
 

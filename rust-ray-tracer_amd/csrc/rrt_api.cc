@@ -267,9 +267,10 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
             // a mesh may use every level the (already built) top level leaves free
             const uint32_t budget = db.mesh >= 0 && hs.top_depth > 0u && hs.top_depth + 2u <= MAX_TREE_DEPTH
                                         ? MAX_TREE_DEPTH - hs.top_depth - 1u : db.budget;
-            // RRT_LBVH_CLUSTER: primitives per subtree below which the GPU's radix tree is kept (above it the host's SAH
-            // builder arranges the subtrees); 0: the plain radix tree
-            uint32_t cluster = 16u;
+            // RRT_LBVH_CLUSTER: primitives per subtree of the GPU's radix tree below which the GPU arranges the primitives
+            // (up to 64: surface-area heuristic, one wavefront per subtree; above: the radix tree is kept) and above
+            // which the host's SAH builder arranges the subtrees; 0: the plain radix tree
+            uint32_t cluster = 64u;
             if (const char* e = std::getenv("RRT_LBVH_CLUSTER")) cluster = (uint32_t)std::max(0, std::atoi(e));
             const hipError_t e = lbvh_build(db.prims.data(), (uint32_t)db.prims.size(), db.grid, (QNode*)c->d_nodes, db.node_base,
                                             (TriRec*)c->d_tris, db.tri_base, db.tri_count, budget, cluster, build_threads(), &r,

@@ -9,6 +9,13 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _verified_builds(monkeypatch):
+    """Every tree the GPU builds in these tests is walked on the host before a kernel traverses it (node slots in range
+    and reached once, every triangle in exactly one leaf, depth as reported): a broken tree fails the upload."""
+    monkeypatch.setenv("RRT_LBVH_VERIFY", "1")
+
+
 def same_bits(a, b):
     """Bitwise equality of two hit arrays (a sphere's far-root uv is NaN, which never compares equal to itself)."""
     return a.tobytes() == b.tobytes()
@@ -117,12 +124,20 @@ def test_rebuilt_upper_levels_bound_the_depth_of_a_chain(rrt, oracle, monkeypatc
     o = oracle.OracleScene(s)
     rays = np.concatenate([helpers.primary_rays(o, 256, 256, 4096, seed=3), helpers.bounce_rays(o, helpers.primary_rays(o, 256, 256, 2048, seed=4), seed=5)])
     assert same_bits(r.intersect(rays), host.intersect(rays))
-    for cluster in ("2", "3", "7", "100000"):  # odd cut sizes; a cut above the whole tree keeps the radix tree (and falls back)
+    # odd cut sizes (up to 64 the GPU rebuilds the subtrees below the cut, above it they keep their radix topology); a cut
+    # above the whole tree keeps the radix tree (and falls back)
+    for cluster in ("2", "3", "7", "16", "65", "100000"):
         monkeypatch.setenv("RRT_LBVH_CLUSTER", cluster)
         rr = rrt.Renderer(device_build=True)
         rr.upload(s)
         assert same_bits(rr.intersect(rays), host.intersect(rays)), cluster
         rr.close()
+    monkeypatch.delenv("RRT_LBVH_CLUSTER")
+    monkeypatch.setenv("RRT_LBVH_SAH", "0")  # the default cut with the radix topology below it
+    rr = rrt.Renderer(device_build=True)
+    rr.upload(s)
+    assert same_bits(rr.intersect(rays), host.intersect(rays))
+    rr.close()
     host.close()
     r.close()
 
