@@ -313,8 +313,8 @@ __global__ void k_permute_tris(const LeafInfo* __restrict__ leaf, const uint32_t
 // segmented scans, and takes the cheapest split of the three axes (full sweep, the host builder's cost: area x count).
 // Triangle segments end as leaves by the host builder's rule (count <= node cost + split cost / area).  The subtree's
 // nodes go into the slots of the radix nodes they replace: a radix subtree over sorted positions [f, l] owns the
-// slots f..l-1 (root at f) or f+1..l (root at l), one per gap between neighbouring positions, and the root keeps its
-// slot, so whatever refers to the subtree stays valid.
+// slots f..l-1 (root at f) or f+1..l (root at l), and the root keeps its slot, so whatever refers to the subtree stays
+// valid.  While it is built, a node is named by the gap between neighbouring positions at which it splits its segment.
 constexpr int CL_MAX = 64;          // primitives per rebuilt subtree
 constexpr int CL_WAVES = 4;         // wavefronts per workgroup
 constexpr uint32_t CL_LEVELS = 10;  // node levels a rebuilt subtree may have (a balanced tree over 64 primitives needs 6)
@@ -393,6 +393,7 @@ __global__ __launch_bounds__(CL_MAX * CL_WAVES) void k_cluster_sah(
     uint32_t* __restrict__ tri_prefix, NodeState* __restrict__ st, QNode* __restrict__ nodes, Grid g, uint32_t node_base, uint32_t tri_base,
     uint32_t leaf_tris, float node_cost, uint32_t* __restrict__ failed) {
     __shared__ QNode s_nodes[CL_WAVES][CL_MAX];
+    __shared__ uint8_t s_rank[CL_WAVES][CL_MAX];
     const int lane = (int)(threadIdx.x & 63u), w = (int)(threadIdx.x >> 6);
     const uint32_t ci = blockIdx.x * CL_WAVES + (uint32_t)w;
     if (ci >= *root_count) return;  // the whole wavefront leaves; the kernel has no workgroup barrier
@@ -415,7 +416,8 @@ __global__ __launch_bounds__(CL_MAX * CL_WAVES) void k_cluster_sah(
     const uint32_t tri0 = tri_prefix[t.first];
     int lo = valid ? 0 : lane, hi = valid ? k : lane + 1;
     bool done = !valid;
-    int parent_gap = -1, side = 0, root_gap = 0;
+    int parent_gap = -1, side = 0;
+    uint32_t gap_level = 0xFFFFu;  // lane g: the level at which the node that splits between positions g and g + 1 was made
     uint32_t depth_here = 0u;
     unsigned long long used = 0ull;
     float cmn[3] = {0.f, 0.f, 0.f}, cmx[3] = {0.f, 0.f, 0.f};  // the subtree's box
@@ -498,7 +500,7 @@ __global__ __launch_bounds__(CL_MAX * CL_WAVES) void k_cluster_sah(
             }
         }
         used |= __ballot(eval && lane == split);
-        if (level == 0u) root_gap = __shfl(split, 0, 64);
+        if (eval && lane == split) gap_level = level;
 
         // --- what this segment is goes into its parent's node
         if ((eval || make_leaf) && lane == lo && parent_gap >= 0) {
@@ -542,11 +544,19 @@ __global__ __launch_bounds__(CL_MAX * CL_WAVES) void k_cluster_sah(
     }
     const unsigned long long tri_final = __ballot(kind == KIND_TRI);
     if (valid) tri_prefix[t.first + lane] = tri0 + (uint32_t)__popcll(tri_final & ((1ull << lane) - 1ull));
-    const uint32_t slot0 = c == (uint32_t)t.first ? (uint32_t)t.first : (uint32_t)t.first + 1u;  // first of the k - 1 slots
-    const int root_at = c == (uint32_t)t.first ? 0 : k - 2;                                      // where the root's slot is among them
+    // The nodes take the subtree's slots level by level, left to right: the two children of a node are then neighbours
+    // (nothing else of their level lies between them), and the slots that stay unused -- leaves of several triangles
+    // need fewer nodes than the radix tree had -- are together at the end instead of between the nodes.  The root is
+    // first in this order and must keep its own slot, the first or the last of the run: the order runs from there.
+    const unsigned long long order = wave_sort(((unsigned long long)gap_level << 6) | (unsigned long long)lane, lane);
+    s_rank[w][(int)(order & 63ull)] = (uint8_t)lane;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const bool root_first = c == (uint32_t)t.first;
+    const uint32_t run0 = node_base + (root_first ? (uint32_t)t.first : (uint32_t)t.first + 1u);  // first of the k - 1 slots
     auto slot_of = [&](int gap) -> uint32_t {
-        const int m = gap == root_gap ? root_at : (gap == root_at ? root_gap : gap);
-        return node_base + slot0 + (uint32_t)m;
+        const uint32_t r = s_rank[w][gap];
+        return run0 + (root_first ? r : (uint32_t)(k - 2) - r);
     };
     if (lane < k - 1 && ((used >> lane) & 1ull)) {
         QNode q = s_nodes[w][lane];
