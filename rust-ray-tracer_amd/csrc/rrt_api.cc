@@ -272,6 +272,7 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
             // which the host's SAH builder arranges the subtrees; 0: the plain radix tree
             uint32_t cluster = 64u;
             if (const char* e = std::getenv("RRT_LBVH_CLUSTER")) cluster = (uint32_t)std::max(0, std::atoi(e));
+            const auto tb = std::chrono::steady_clock::now();
             const hipError_t e = lbvh_build(db.prims.data(), (uint32_t)db.prims.size(), db.grid, (QNode*)c->d_nodes, db.node_base,
                                             (TriRec*)c->d_tris, db.tri_base, db.tri_count, budget, cluster, build_threads(), &r,
                                             db.raw_runs.data(), db.raw_runs.size(), db.pad);
@@ -279,6 +280,10 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
                 free_scene(c);
                 return hip_fail(c, e, "rrt_scene_upload: GPU BVH build");
             }
+            if (std::getenv("RRT_BUILD_TRACE"))
+                fprintf(stderr, "[rrt build] GPU BVH: %u primitives, %.1f ms with the upload of the triangles, of it device %.1f ms, upper levels on the host %.1f ms (%u subtrees), depth %u\n",
+                        (unsigned)(db.prims.size() + db.tri_count), std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - tb).count(),
+                        r.build_ms, r.top_ms, r.clusters, r.depth);
             if (r.depth == 0u) { fits = false; break; }
             if (db.mesh < 0) hs.top_depth = r.depth;
             else hs.deepest_mesh = std::max(hs.deepest_mesh, r.depth);

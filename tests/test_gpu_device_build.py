@@ -44,9 +44,11 @@ def test_device_built_scenes_match_the_oracle_and_the_host_build(rrt, oracle, mo
     host.close()
 
 
-def test_full_size_mesh(rrt, oracle):
+@pytest.mark.parametrize("group", ["0", "64"])
+def test_full_size_mesh(rrt, oracle, monkeypatch, group):
     from rust_ray_tracer_amd import scenes
 
+    monkeypatch.setenv("RRT_LBVH_GROUP", group)  # 64: the levels above the subtrees are grouped on the GPU as well
     scene = scenes.synthetic_mesh(rrt, helpers.ASSETS, subdiv=512)
     dev = rrt.Renderer(device_build=True)
     info = dev.upload(scene)
@@ -132,6 +134,15 @@ def test_rebuilt_upper_levels_bound_the_depth_of_a_chain(rrt, oracle, monkeypatc
         rr.upload(s)
         assert same_bits(rr.intersect(rays), host.intersect(rays)), cluster
         rr.close()
+    # a second round of the GPU's subtree builder over the finished subtrees (groups of up to 3, 8, 64 of them)
+    for cluster, group in (("2", "3"), ("5", "8"), ("16", "64")):
+        monkeypatch.setenv("RRT_LBVH_CLUSTER", cluster)
+        monkeypatch.setenv("RRT_LBVH_GROUP", group)
+        rr = rrt.Renderer(device_build=True)
+        assert rr.upload(s).device_built == 1
+        assert same_bits(rr.intersect(rays), host.intersect(rays)), (cluster, group)
+        rr.close()
+    monkeypatch.delenv("RRT_LBVH_GROUP")
     monkeypatch.delenv("RRT_LBVH_CLUSTER")
     monkeypatch.setenv("RRT_LBVH_SAH", "0")  # the default cut with the radix topology below it
     rr = rrt.Renderer(device_build=True)
