@@ -212,6 +212,9 @@ typedef struct rrt_scene_info {
     float upload_ms;
     uint32_t device_built;   /* number of BVHs the GPU builder built                      */
     uint32_t unrolled_instances; /* instances written out into the top-level BVH (0: none, or RRT_CFG_NO_UNROLL) */
+    uint32_t scaled_slab;    /* 1: rrt_render walks this scene with the scaled form of the box arithmetic (one grid,
+                                camera ray directions between 2^-24 and 2^24 long); 0: with the convert form.  Same images. */
+    uint32_t reserved;
 } rrt_scene_info;
 
 /* ---- lifetime ----  replaces: process start-up in reference src/main.rs:26-56 */

@@ -126,7 +126,8 @@ class Stats(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("prim_count", C.c_uint32), ("node_count", C.c_uint32), ("tri_count", C.c_uint32),
                 ("bvh_depth", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
-                ("upload_ms", C.c_float), ("device_built", C.c_uint32), ("unrolled_instances", C.c_uint32)]
+                ("upload_ms", C.c_float), ("device_built", C.c_uint32), ("unrolled_instances", C.c_uint32),
+                ("scaled_slab", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GltfOptions(C.Structure):

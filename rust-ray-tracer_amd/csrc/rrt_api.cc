@@ -3,7 +3,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is opened at run time, when a group spans several GPUs
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -134,6 +136,36 @@ rrt_status stage(rrt_ctx* c, int slot, size_t bytes, void** out) {
 rrt_status order_after_pending(rrt_ctx* c, hipStream_t s) {
     if (c->render_pending && s != c->last_stream) RRT_HIP(c, hipStreamWaitEvent(s, c->ev_stop, 0));
     return RRT_OK;
+}
+
+// Scale of the render kernels' scaled slab arithmetic (rrt_device.h: trav_set_ray_scaled), or sigma = 0 where that form
+// is not valid: it needs a grid whose steps are finite, positive and within 2^20 of each other, a scale that is a
+// normal float with room to spare, and camera rays whose direction components stay far inside [2^-40, 2^40] (checked
+// at nine points of the frame against [2^-24, 2^24]; scattered directions have length 1 or at most 2).
+void set_slab_scale(SceneDev& S) {
+    S.sigma = 0.0f;
+    for (int a = 0; a < 3; ++a) S.step_scaled[a] = 0.0f;
+    const float* st = S.grid.step;
+    const float step_max = std::max(st[0], std::max(st[1], st[2])), step_min = std::min(st[0], std::min(st[1], st[2]));
+    if (!(step_min > 0.0f) || !std::isfinite(step_max) || !(step_min >= step_max * 0x1p-20f)) return;
+    int e = 0;
+    (void)std::frexp(step_max, &e);  // step_max = m * 2^e, m in [0.5, 1)
+    const int se = 49 - e;           // step_max * 2^se lies in [2^48, 2^49)
+    if (se - 149 < -120 || se - 149 > -40) return;  // sigma = 2^(se - 149): a scene extent between 2^-44 and 2^36
+    const CameraRec& cam = S.cam;
+    for (int iy = -1; iy <= 1; ++iy)
+        for (int ix = -1; ix <= 1; ++ix) {
+            const double px = ix * (double)cam.scale * cam.aspect, py = iy * (double)cam.scale;
+            double len2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double d = cam.c0[a] * px + cam.c1[a] * py - cam.c2[a] + cam.tr[a] - cam.origin[a];
+                len2 += d * d;
+            }
+            const double len = std::sqrt(len2);
+            if (!(len >= 0x1p-24) || !(len <= 0x1p24)) return;
+        }
+    S.sigma = std::ldexp(1.0f, se - 149);
+    for (int a = 0; a < 3; ++a) S.step_scaled[a] = (float)std::ldexp((double)st[a], se);
 }
 
 // Instances are unrolled into the top-level BVH unless the context (RRT_CFG_NO_UNROLL) or the environment
@@ -320,12 +352,14 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
     S.max_depth = c->cfg.max_depth;
     S.seed = c->cfg.seed;
     S.grid = hs.grid;
+    set_slab_scale(S);
 
     c->info.prim_count = hs.prim_count;
     c->info.node_count = (uint32_t)hs.qnodes.size() + hs.tail_nodes;
     c->info.tri_count = (uint32_t)hs.tris.size() + hs.tail_tris;
     c->info.bvh_depth = hs.depth;
     c->info.unrolled_instances = hs.unrolled_instances;
+    c->info.scaled_slab = (S.sigma != 0.0f && !hs.has_instances) ? 1u : 0u;
     c->info.device_bytes = total;
     c->info.build_ms = build_ms;
     c->info.upload_ms = upload_ms;
@@ -361,6 +395,13 @@ rrt_status rrt_scene_check(const rrt_scene_desc* scene, rrt_scene_info* out) {
     out->tri_count = (uint32_t)hs.tris.size() + hs.tail_tris;
     out->bvh_depth = hs.depth;
     out->unrolled_instances = hs.unrolled_instances;
+    {
+        SceneDev tmp{};
+        tmp.cam = hs.cam;
+        tmp.grid = hs.grid;
+        set_slab_scale(tmp);
+        out->scaled_slab = (tmp.sigma != 0.0f && !hs.has_instances) ? 1u : 0u;
+    }
     auto sz = [](size_t n, size_t rec) { return (uint64_t)(n ? n : 1) * rec; };
     out->device_bytes = sz(hs.qnodes.size() + hs.tail_nodes, sizeof(QNode)) + sz(hs.tris.size() + hs.tail_tris, sizeof(TriRec)) + sz(hs.spheres.size(), sizeof(SphereRec)) +
                         sz(hs.rects.size(), sizeof(RectRec)) + sz(hs.insts.size() + 1u, sizeof(InstRec)) + sz(hs.mats.size(), sizeof(MatRec)) +
@@ -493,6 +534,7 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     if (const char* e = std::getenv("RRT_LEAVE_READY")) tuning.leave_ready = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
     if (const char* e = std::getenv("RRT_OVERLAP_ITEMS")) tuning.overlap_items = std::atoi(e) != 0 ? 1u : 0u;
     if (const char* e = std::getenv("RRT_BAND_TILES")) tuning.band_tiles = (uint32_t)std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("RRT_SCALED_SLAB")) tuning.scaled_slab = std::atoi(e) != 0 ? 1u : 0u;
     if (rrt_status st = order_after_pending(c, s)) return st;
     RRT_HIP(c, hipMemsetAsync(d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));

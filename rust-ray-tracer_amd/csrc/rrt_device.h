@@ -408,10 +408,45 @@ __device__ __forceinline__ void slab_pair(uint32_t w, uint32_t rot, float a, flo
     t_out = __builtin_fmaf((float)(v >> 16), a, b);
 }
 
-template <int MODE>
+// Scaled form of the slab arithmetic (SCALED; the render kernels on scenes walked on ONE grid).  A 16-bit plane index
+// q, read as the bit pattern of a float, IS the float q * 2^-149 (a denormal), so extracting a half of a node's dword
+// (one AND or one shift, full-rate instructions) replaces the integer-to-float convert (a half-rate instruction, twelve
+// of them per node step).  The multiplier absorbs the 2^149, which only fits the float range if plane distances are
+// formed on a smaller scale: the node step works on tau = t * sigma, sigma a power of two chosen per grid so that the
+// largest of step * sigma * 2^149 lies in [2^48, 2^49).  Scaling by a power of two is exact, so
+// fma(asfloat(q), A, B) with A = step * sigma * 2^149 * inv and B = (origin - o) * inv * sigma is the unscaled
+// fma(float(q), step * inv, (origin - o) * inv) times sigma bit for bit (tools/valu_class.hip checks all 65536
+// indices) as long as nothing leaves the normal range: inv is clamped to +-2^78 instead of +-1e30 (A stays below
+// 2^127), which is a box test for a ray whose direction component is at least 2^-78 in magnitude: for such a
+// near-parallel ray the slab's two distances stay on either side of every t the ray can reach inside the scene, as
+// with the larger clamp.  Entry distances are clamped to [0, 1] by the fma itself (tau = 1 is 2^100 grid steps away),
+// which replaces the max with t_min by the weaker, still conservative t >= 0.
+// Valid while tau stays clear of the ends of the float range: for rays whose direction is between 2^-40 and 2^40 long,
+// i.e. the render kernels' rays (the host checks the camera's, scattered directions have length 1 or at most 2) and
+// not the ray batches of rrt_intersect, whose kernels keep the convert form.  Either form only has to be conservative:
+// hits are decided by the primitive tests, so images do not depend on which one ran.
+static constexpr float SLAB_INV_MAX_SCALED = 0x1p78f;
+__device__ __forceinline__ float slab_rcp_scaled(float d) {
+    return fmaxf(fminf(__builtin_amdgcn_rcpf(d), SLAB_INV_MAX_SCALED), -SLAB_INV_MAX_SCALED);
+}
+__device__ __forceinline__ void trav_set_ray_scaled(Trav& T, V3 o, V3 d, const SceneDev& S) {
+    const V3 inv = v3(slab_rcp_scaled(d.x), slab_rcp_scaled(d.y), slab_rcp_scaled(d.z));
+    T.ga = v3(S.step_scaled[0] * inv.x, S.step_scaled[1] * inv.y, S.step_scaled[2] * inv.z);
+    // (scaled before the multiplication by inv: a distant origin times a clamped inv must not overflow)
+    T.gb = v3(((S.grid.origin[0] - o.x) * S.sigma) * inv.x, ((S.grid.origin[1] - o.y) * S.sigma) * inv.y,
+              ((S.grid.origin[2] - o.z) * S.sigma) * inv.z);
+}
+__device__ __forceinline__ void slab_pair_scaled(uint32_t w, uint32_t rot, float a, float b, float& t_in, float& t_out) {
+    const uint32_t v = __builtin_amdgcn_alignbit(w, w, rot);
+    t_in = __builtin_amdgcn_fmed3f(__builtin_fmaf(__uint_as_float(v & 0xFFFFu), a, b), 0.0f, 1.0f);
+    t_out = __builtin_fmaf(__uint_as_float(v >> 16), a, b);
+}
+
+template <int MODE, bool SCALED = false>
 __device__ __forceinline__ void trav_begin(const SceneDev& S, V3 o, V3 d, float tmax, lds_int* stack, int stride, Trav& T) {
     T.best.t = tmax; T.best.u = 0.f; T.best.v = 0.f; T.best.what = WHAT_NONE; T.best.inst = -1;
-    trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
+    if (SCALED) trav_set_ray_scaled(T, o, d, S);
+    else trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
     T.cur_inst = -1;
     stack[0] = REF_DONE;
     T.top = stack + stride;
@@ -431,12 +466,14 @@ __device__ __forceinline__ bool trav_due(int cur) { return (uint32_t)cur - (REF_
 // the few lanes that need it.  `o`, `d`: the lane's ray in the space it is walking (only touched when INST: replaced
 // by the object-space ray on entering an instance and by the parked world-space ray on leaving it); `wray`: the lane's
 // slot of the parked world rays (INST only).
-template <int MODE, bool COUNT, int K = 0, int STEPS = 1>
+template <int MODE, bool COUNT, int K = 0, int STEPS = 1, bool SCALED = false>
 __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, float tmin, int stride, Trav& T,
                                            TraceCounters& cnt, uint32_t min_lanes, lds_int* lim = nullptr, int* deep = nullptr,
                                            lds_float* wray = nullptr) {
     constexpr bool INST = MODE == MODE_TWO_LEVEL;
+    static_assert(!(SCALED && INST), "the scaled slab arithmetic is for scenes walked on one grid");
     V3 ga = T.ga, gb = T.gb;
+    const float bt_scaled = T.best.t * S.sigma;  // the closest hit so far on the node step's scale (a pass never changes it)
     // rotate count of a node's plane pair: 16 where the ray runs against the axis (the sign of ga, the grid step
     // being positive), else 0
     uint32_t rx = (__float_as_uint(ga.x) >> 31) << 4, ry = (__float_as_uint(ga.y) >> 31) << 4, rz = (__float_as_uint(ga.z) >> 31) << 4;
@@ -458,18 +495,32 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
             if (first_active_lane()) cnt.wave_nodes++;
         }
         float ix, iy, iz, ox, oy, oz;
-        // left box
-        slab_pair(a.z, rx, ga.x, gb.x, ix, ox);
-        slab_pair(a.w, ry, ga.y, gb.y, iy, oy);
-        slab_pair(b.x, rz, ga.z, gb.z, iz, oz);
-        const float ln = fmaxf(fmaxf(fmaxf(ix, iy), iz), tmin);
-        const float lf = fminf(fminf(fminf(ox, oy), oz), T.best.t);
-        // right box
-        slab_pair(b.y, rx, ga.x, gb.x, ix, ox);
-        slab_pair(b.z, ry, ga.y, gb.y, iy, oy);
-        slab_pair(b.w, rz, ga.z, gb.z, iz, oz);
-        const float rn = fmaxf(fmaxf(fmaxf(ix, iy), iz), tmin);
-        const float rf = fminf(fminf(fminf(ox, oy), oz), T.best.t);
+        float ln, lf, rn, rf;
+        if (SCALED) {
+            slab_pair_scaled(a.z, rx, ga.x, gb.x, ix, ox);
+            slab_pair_scaled(a.w, ry, ga.y, gb.y, iy, oy);
+            slab_pair_scaled(b.x, rz, ga.z, gb.z, iz, oz);
+            ln = fmaxf(fmaxf(ix, iy), iz);
+            lf = fminf(fminf(fminf(ox, oy), oz), bt_scaled);
+            slab_pair_scaled(b.y, rx, ga.x, gb.x, ix, ox);
+            slab_pair_scaled(b.z, ry, ga.y, gb.y, iy, oy);
+            slab_pair_scaled(b.w, rz, ga.z, gb.z, iz, oz);
+            rn = fmaxf(fmaxf(ix, iy), iz);
+            rf = fminf(fminf(fminf(ox, oy), oz), bt_scaled);
+        } else {
+            // left box
+            slab_pair(a.z, rx, ga.x, gb.x, ix, ox);
+            slab_pair(a.w, ry, ga.y, gb.y, iy, oy);
+            slab_pair(b.x, rz, ga.z, gb.z, iz, oz);
+            ln = fmaxf(fmaxf(fmaxf(ix, iy), iz), tmin);
+            lf = fminf(fminf(fminf(ox, oy), oz), T.best.t);
+            // right box
+            slab_pair(b.y, rx, ga.x, gb.x, ix, ox);
+            slab_pair(b.z, ry, ga.y, gb.y, iy, oy);
+            slab_pair(b.w, rz, ga.z, gb.z, iz, oz);
+            rn = fmaxf(fmaxf(fmaxf(ix, iy), iz), tmin);
+            rf = fminf(fminf(fminf(ox, oy), oz), T.best.t);
+        }
         const bool hl = ln <= lf, hr = rn <= rf;
         const bool any = hl || hr, both = hl && hr;
         int left = (int)a.x, right = (int)a.y;

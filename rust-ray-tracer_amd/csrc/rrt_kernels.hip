@@ -63,11 +63,14 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_ONE_ITEM_WAVES
 #define RRT_ONE_ITEM_WAVES 6  // workgroups per CU the one-item form (small scenes) is compiled for
 #endif
-template <int MODE, bool COUNT, bool PIPELINED>
+// SCALED: the node steps use the scaled form of the slab arithmetic (rrt_device.h: trav_set_ray_scaled), which the host
+// selects when the scene is walked on one grid and its camera's ray directions are of ordinary magnitude.
+template <int MODE, bool COUNT, bool PIPELINED, bool SCALED>
 __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? RRT_UNROLLED_WAVES : 7) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
     constexpr bool INST = MODE == MODE_TWO_LEVEL;
+    static_assert(!(SCALED && INST), "the scaled slab arithmetic is for scenes walked on one grid");
     // RENDER_STACK entries per lane of the traversal stack live in LDS, the rest in private memory (six workgroups per
     // CU, seven in the pipelined form, whose large scenes gain more from the extra wavefront than they lose to its
     // spills).  Instanced scenes add six floats per lane for the world-space ray of a lane that walks inside a mesh.
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 camera_ray(S.cam, u, v, width, height, o, d);
                 beta = v3(1.f, 1.f, 1.f);
                 depth = S.max_depth;
-                trav_begin<MODE>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
             }
 
             for (;;) {
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
                             const uint32_t nodes0 = cnt.nodes;
-                            trav_nodes<MODE, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                            trav_nodes<MODE, COUNT, K, 2, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                             uint32_t steps = cnt.nodes - nodes0;
                             for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                             if (lane == 0u) {
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                                 slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                             }
                         } else {
-                            trav_nodes<MODE, COUNT, K, 2>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                            trav_nodes<MODE, COUNT, K, 2, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         }
                     }
                     if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                             has_ray = false;
                         }
                     }
-                    if (has_ray) trav_begin<MODE>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                    if (has_ray) trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
                 }
                 if (__ballot(has_ray) == 0ull) break;  // every lane has rendered all samples of this item
             }
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<MODE, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, 3, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                         if (lane == 0u) {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                             slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                         }
                     } else {
-                        trav_nodes<MODE, COUNT, K, 3>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, 3, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                     }
                 }
                 if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         has_ray = true;
                     }
                 }
-                if (has_ray) trav_begin<MODE>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                if (has_ray) trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
             }
         }
     }
@@ -657,14 +660,14 @@ uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t s
     return (uint32_t)n;
 }
 
-template <int MODE, bool COUNT, bool PIPELINED>
+template <int MODE, bool COUNT, bool PIPELINED, bool SCALED = false>
 static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, float* out, unsigned long long* d_counters,
                                         unsigned int* d_heads, int cu_count, hipStream_t stream) {
     // persistent grid: as many workgroups as the chip holds at once (never more than there are work items)
     static int blocks_per_cu = 0;  // per template instantiation
     if (blocks_per_cu == 0) {
         int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<MODE, COUNT, PIPELINED>, RENDER_BLOCK, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<MODE, COUNT, PIPELINED, SCALED>, RENDER_BLOCK, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = n > 0 ? n : 1;
         // experiment knob: fewer resident workgroups per CU (occupancy sensitivity)
@@ -677,7 +680,7 @@ static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, 
     const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;
     if (blocks > needed) blocks = needed;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
+    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED, SCALED>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
     return hipGetLastError();
 }
 
@@ -703,8 +706,18 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     hipError_t e;
     // the pipelined form packs a lane's pixel coordinates into 16 bits each
     const bool pipelined = tuning.overlap_items != 0u && width < 65536u && height < 65536u;
-    const unsigned variant = ((unsigned)mode << 2) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
+    // the scaled slab arithmetic where the host found it valid for this scene (S.sigma != 0) and the walk stays on one grid
+    const bool scaled = S.sigma != 0.0f && tuning.scaled_slab != 0u && mode != MODE_TWO_LEVEL;
+    const unsigned variant = (scaled ? 16u : 0u) | ((unsigned)mode << 2) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
     switch (variant) {
+        case 27u: e = launch_render_variant<MODE_UNROLLED, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 26u: e = launch_render_variant<MODE_UNROLLED, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 25u: e = launch_render_variant<MODE_UNROLLED, false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 24u: e = launch_render_variant<MODE_UNROLLED, false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 19u: e = launch_render_variant<MODE_FLAT, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 18u: e = launch_render_variant<MODE_FLAT, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 17u: e = launch_render_variant<MODE_FLAT, false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 16u: e = launch_render_variant<MODE_FLAT, false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
         case 11u: e = launch_render_variant<MODE_UNROLLED, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
         case 10u: e = launch_render_variant<MODE_UNROLLED, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
         case 9u: e = launch_render_variant<MODE_UNROLLED, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;

@@ -160,6 +160,10 @@ struct SceneDev {
     uint32_t seed;
     float light_weight;  // 1.0f / light_count
     Grid grid;          // grid of the top-level BVH (world space)
+    // scaled slab arithmetic of the render kernels (rrt_device.h, trav_set_ray_scaled): sigma = the power of two that
+    // puts the largest of grid.step * sigma * 2^149 into [2^48, 2^49); step_scaled = grid.step * sigma * 2^149
+    float step_scaled[3];
+    float sigma;
 };
 
 // Launch geometry of the render kernel.  The frame is cut into 8x8 pixel tiles and the sample range into

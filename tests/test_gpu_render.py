@@ -178,6 +178,65 @@ def test_image_does_not_depend_on_wave_scheduling(rrt, monkeypatch, name):
     r.close()
 
 
+@pytest.mark.parametrize("name", ["default", "suzanne", "mixed", "cornell", "synthetic", "instanced_tris"])
+def test_image_does_not_depend_on_the_form_of_the_box_test(rrt, monkeypatch, name):
+    """The render kernels' node steps form plane distances either from converted plane indices or, on scenes walked on
+    one grid, from the indices' bit patterns read as (denormal) floats on a scaled t axis (RRT_SCALED_SLAB, default on).
+    Both box tests are conservative and the primitive tests decide, so rays and images are identical bit for bit."""
+    r = rrt.Renderer(seed=13)
+    assert r.upload(helpers.SCENES[name](rrt)).scaled_slab == 1
+    for overlap in ("0", "1"):
+        monkeypatch.setenv("RRT_OVERLAP_ITEMS", overlap)
+        monkeypatch.setenv("RRT_SCALED_SLAB", "0")
+        plain, s0 = r.render(120, 68, 8)
+        monkeypatch.setenv("RRT_SCALED_SLAB", "1")
+        scaled, s1 = r.render(120, 68, 8)
+        assert s0.rays == s1.rays and np.array_equal(plain, scaled), (name, overlap)
+    r.close()
+
+
+def test_scaled_box_test_with_hostile_coordinates(rrt, oracle, monkeypatch):
+    """The scaled form of the box test on triangle soups far from the origin, tiny or huge, flat in one axis, seen from
+    outside and from inside along an axis; and cameras whose ray directions are too long or too short for it, for which
+    the upload must choose the convert form.  Same image as the convert form bit for bit, and as the oracle's."""
+    g = np.random.default_rng(77)
+    cases = [(1.0, 0.0, None, 1.0), (1e-3, 0.0, None, 1.0), (1e4, 0.0, None, 1.0), (1.0, 1e4, None, 1.0), (50.0, -2e5, None, 1.0),
+             (1.0, 0.0, 1, 1.0), (10.0, 500.0, 2, 1.0), (1.0, 7.0, None, 1e-6), (1.0, 7.0, None, 100.0), (1.0, 0.0, None, 1e-9),
+             (1.0, 0.0, None, 1e9)]
+    for scale, offset, flat_axis, cam_len in cases:
+        n = 1200
+        centres = g.uniform(-1, 1, (n, 1, 3)) * scale
+        tris = centres + g.normal(0, 0.05 * scale, (n, 3, 3))
+        if flat_axis is not None:
+            tris[..., flat_axis] = 0.25 * scale
+            tris[n // 2:, 1, :], tris[n // 2:, 2, :] = tris[n // 2:, 2, :].copy(), tris[n // 2:, 1, :].copy()
+        tris = (tris + offset).astype(np.float32)
+        s = rrt.Scene()
+        m = s.add_material(rrt.Lambertian(0.7, 0.6, 0.5))
+        metal = s.add_material(rrt.Metal((0.8, 0.8, 0.9), 0.0))
+        s.add_triangles(tris[: n // 2], m)
+        s.add_triangles(tris[n // 2:], metal)
+        s.background = (0.6, 0.7, 0.9)
+        # the camera looks down the z axis (the central rays are close to axis-parallel); its matrix is scaled by
+        # cam_len, which scales every ray direction and leaves the image unchanged
+        c2w = np.float32([[cam_len, 0, 0, offset], [0, cam_len, 0, offset], [0, 0, cam_len, offset + 3 * scale]])
+        s.camera = rrt.Camera(1.0, 40.0, c2w)
+        r = rrt.Renderer(seed=21)
+        assert r.upload(s).scaled_slab == (1 if 1e-7 < cam_len < 1e7 else 0)
+        w, h, spp = 64, 48, 4
+        monkeypatch.setenv("RRT_SCALED_SLAB", "0")
+        plain, s0 = r.render(w, h, spp)
+        monkeypatch.setenv("RRT_SCALED_SLAB", "1")
+        scaled, s1 = r.render(w, h, spp)
+        monkeypatch.delenv("RRT_SCALED_SLAB")
+        assert s0.rays == s1.rays and np.array_equal(plain, scaled), (scale, offset, flat_axis, cam_len)
+        ref, ref_rays = oracle.OracleScene(s).render(w, h, spp, seed=21)
+        assert abs(int(s1.rays) - ref_rays) <= max(2, ref_rays // 500), (scale, offset, flat_axis, cam_len)
+        close = np.isclose(scaled, ref, rtol=1e-4, atol=1e-5).all(axis=-1)
+        assert close.mean() >= 0.99, (close.mean(), scale, offset, flat_axis, cam_len)
+        r.close()
+
+
 def test_unrolled_and_two_level_instances_render_the_same_image(rrt):
     """The unrolled form of an instanced scene (default for triangle-only meshes) and the two-level form follow the same
     paths: identical ray counts and images, bit for bit."""
