@@ -521,8 +521,6 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
             rn = fmaxf(fmaxf(fmaxf(ix, iy), iz), tmin);
             rf = fminf(fminf(fminf(ox, oy), oz), T.best.t);
         }
-        const bool hl = ln <= lf, hr = rn <= rf;
-        const bool any = hl || hr, both = hl && hr;
         int left = (int)a.x, right = (int)a.y;
         if (K == 0 || WINDOW) {
             // Every lane's stack top is inside the LDS part: the step is finished without a branch.  Scalar and
@@ -531,7 +529,13 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
             // written above the top, the top moves up if both children are hit and down if neither is, and the entry
             // read back is the popped one exactly when neither is hit.  Entries touched: 0 .. K-1 (K == 0: the whole
             // stack is in LDS and has one entry more than the deepest walk needs).
-            const bool right_first = hr & (!hl | (rn < ln));  // bitwise on purpose: no short-circuit branches
+            // The hit flags are combined as wavefront masks (scalar instructions): written on per-lane booleans, the
+            // negation of a compare is compiled as a second vector compare, and compares are half-rate instructions.
+            const unsigned long long hl_m = __builtin_amdgcn_ballot_w64(ln <= lf), hr_m = __builtin_amdgcn_ballot_w64(rn <= rf);
+            const unsigned long long closer_m = __builtin_amdgcn_ballot_w64(rn < ln);
+            // the right child first if it is hit and the left one is not, or is entered later
+            const bool right_first = __builtin_amdgcn_inverse_ballot_w64(hr_m & ~(hl_m & ~closer_m));
+            const bool any = __builtin_amdgcn_inverse_ballot_w64(hl_m | hr_m), both = __builtin_amdgcn_inverse_ballot_w64(hl_m & hr_m);
             const int near = right_first ? right : left;
             const int far = right_first ? left : right;
             *top = far;
@@ -539,13 +543,13 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
             top = both ? top + stride : rd;
             const int popped = *rd;
             cur = any ? near : popped;
-        } else if (both) {
+        } else if (ln <= lf && rn <= rf) {
             if (rn < ln) { int tmp = left; left = right; right = tmp; }
             stack_push<K>(top, stride, lim, deep, right);
             cur = left;
-        } else if (hl) {
+        } else if (ln <= lf) {
             cur = left;
-        } else if (hr) {
+        } else if (rn <= rf) {
             cur = right;
         } else {
             cur = stack_pop<K>(top, stride, lim, deep);

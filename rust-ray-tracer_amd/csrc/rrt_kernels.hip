@@ -57,6 +57,12 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
     return (uint32_t)(((unsigned long long)q * n_work) / N_QUEUES);
 }
 
+#ifndef RRT_PIPE_STEPS
+#define RRT_PIPE_STEPS 5  // node steps between two continuation votes of a node pass, pipelined form
+#endif
+#ifndef RRT_ONE_STEPS
+#define RRT_ONE_STEPS 2  // ... and in the one-item form
+#endif
 #ifndef RRT_UNROLLED_WAVES
 #define RRT_UNROLLED_WAVES 7  // workgroups per CU the pipelined form is compiled for on unrolled scenes
 #endif
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                             // idle lane slots of this node pass, by what the idle lanes are waiting for
                             // (the pass is as long as the lane that stayed in it longest)
                             const uint32_t nodes0 = cnt.nodes;
-                            trav_nodes<MODE, COUNT, K, 2, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                            trav_nodes<MODE, COUNT, K, RRT_ONE_STEPS, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                             uint32_t steps = cnt.nodes - nodes0;
                             for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                             if (lane == 0u) {
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                                 slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                             }
                         } else {
-                            trav_nodes<MODE, COUNT, K, 2, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                            trav_nodes<MODE, COUNT, K, RRT_ONE_STEPS, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         }
                     }
                     if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<MODE, COUNT, K, 3, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, RRT_PIPE_STEPS, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
                         if (lane == 0u) {
@@ -328,7 +334,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                             slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                         }
                     } else {
-                        trav_nodes<MODE, COUNT, K, 3, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, RRT_PIPE_STEPS, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                     }
                 }
                 if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);

@@ -184,7 +184,8 @@ def test_image_does_not_depend_on_the_form_of_the_box_test(rrt, monkeypatch, nam
     one grid, from the indices' bit patterns read as (denormal) floats on a scaled t axis (RRT_SCALED_SLAB, default on).
     Both box tests are conservative and the primitive tests decide, so rays and images are identical bit for bit."""
     r = rrt.Renderer(seed=13)
-    assert r.upload(helpers.SCENES[name](rrt)).scaled_slab == 1
+    # (the Cornell box keeps its two rotated boxes as instances of rectangle meshes: a two-level walk, convert form only)
+    assert r.upload(helpers.SCENES[name](rrt)).scaled_slab == (0 if name == "cornell" else 1)
     for overlap in ("0", "1"):
         monkeypatch.setenv("RRT_OVERLAP_ITEMS", overlap)
         monkeypatch.setenv("RRT_SCALED_SLAB", "0")
