@@ -487,6 +487,12 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
     // every stepping lane's stack top is, and stays for this step, inside the LDS part.
     auto step = [&](auto in_window) {
         constexpr bool WINDOW = decltype(in_window)::value;
+        // The entry a pop would take is read before the node is fetched: its address does not depend on the step's
+        // outcome, and its LDS round trip then runs beside the node's fetch instead of between this step's last
+        // compare and the next step's fetch (a wavefront's steps are one dependent chain; at seven wavefronts per SIMD
+        // the chain's length still shows in the kernel's time).
+        int popped = 0;
+        if (K == 0 || WINDOW) popped = *(top - stride);
         // an inner reference is the node's 32-bit byte offset from the uniform base, which the load takes from scalar registers
         const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
         const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
@@ -539,9 +545,8 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
             const int near = right_first ? right : left;
             const int far = right_first ? left : right;
             *top = far;
-            lds_int* rd = any ? top : top - stride;
-            top = both ? top + stride : rd;
-            const int popped = *rd;
+            lds_int* down = any ? top : top - stride;
+            top = both ? top + stride : down;
             cur = any ? near : popped;
         } else if (ln <= lf && rn <= rf) {
             if (rn < ln) { int tmp = left; left = right; right = tmp; }

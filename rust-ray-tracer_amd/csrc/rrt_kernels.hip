@@ -66,13 +66,16 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_UNROLLED_WAVES
 #define RRT_UNROLLED_WAVES 7  // workgroups per CU the pipelined form is compiled for on unrolled scenes
 #endif
+#ifndef RRT_FLAT_WAVES
+#define RRT_FLAT_WAVES 7  // workgroups per CU the pipelined form is compiled for on scenes without instances
+#endif
 #ifndef RRT_ONE_ITEM_WAVES
 #define RRT_ONE_ITEM_WAVES 6  // workgroups per CU the one-item form (small scenes) is compiled for
 #endif
 // SCALED: the node steps use the scaled form of the slab arithmetic (rrt_device.h: trav_set_ray_scaled), which the host
 // selects when the scene is walked on one grid and its camera's ray directions are of ordinary magnitude.
 template <int MODE, bool COUNT, bool PIPELINED, bool SCALED>
-__global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? RRT_UNROLLED_WAVES : 7) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+__global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? RRT_UNROLLED_WAVES : RRT_FLAT_WAVES) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
     constexpr bool INST = MODE == MODE_TWO_LEVEL;
