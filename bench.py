@@ -290,19 +290,27 @@ def main():
                 "l1_addr_busy_frac": pmc.get("ta_busy_frac"),
                 "waves_per_simd": pmc.get("waves_per_simd"),
                 "pmc_source": f"profiles/pmc_per_launch.json [{args.config}] ({pmc.get('source', 'rocprofv3 --pmc, tools/prof.sh')}), profiled at {pmc.get('spp_per_gpu')} spp, used per ray"})
-            if hbm_frac < 0.10:
-                # HBM sees a few per cent of its peak: what binds is instruction issue
-                roof.update({"bound": "issue", "achieved": valu_rate, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s (VALU)",
-                             "frac": valu_rate / ISSUE_PEAK_GINST})
-            else:
-                roof.update({"bound": "hbm", "achieved": hbm_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac})
-            roof["note"] = ("bound=issue: frac = vector wave-instructions x 2 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz), the share of "
-                            "the SIMDs' issue slots the kernel fills; lane_util_hw = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) is the "
-                            "share of lanes that work in an issued vector instruction.  l1_addr_floor_frac = wavefront load instructions x "
-                            "16 cycles / (256 CUs x kernel cycles): what the loads alone take of each CU's one L1 address unit (16 cycles "
-                            "per load instruction whatever the number of active lanes, tools/l1_rate.hip); l1_addr_busy_frac = TA_BUSY_avr / "
-                            "kernel cycles.  bound=hbm: achieved = HBM bytes (FETCH_SIZE x 2 + "
-                            "WRITE_SIZE) / kernel time.  algorithmic_GBps is served by the caches and is not a fraction of any peak.")
+            # the unit the kernel fills most is the one that bounds it: the SIMDs' issue slots (vector instructions at two
+            # cycles each), the address unit of the vector L1 (16 cycles per wavefront load instruction), or HBM
+            l1_rate = pmc.get("sq_insts_vmem_rd", 0.0) * per_ray * rays_per_step / k_s / 1e9  # G wavefront loads/s
+            l1_peak = CUS * GPU_GHZ / L1_CYCLES_PER_WAVE_LOAD
+            candidates = {
+                "issue": (valu_rate / ISSUE_PEAK_GINST, valu_rate, ISSUE_PEAK_GINST, "G wave-instructions/s (VALU)"),
+                "l1_addr": (l1_rate / l1_peak, l1_rate, l1_peak, "G wavefront load instructions/s"),
+                "hbm": (hbm_frac, hbm_gbps, HBM_PEAK_GBS, "GB/s"),
+            }
+            bound = max(candidates, key=lambda k: candidates[k][0])
+            frac, achieved, peak, unit = candidates[bound]
+            roof.update({"bound": bound, "achieved": achieved, "peak": peak, "unit": unit, "frac": frac})
+            roof["note"] = ("bound = the fullest of three units.  issue: vector wave-instructions x 2 cycles / (1024 SIMDs x kernel cycles at "
+                            "2.4 GHz), the share of the SIMDs' issue slots the kernel fills at the two-cycle rate (half of the kernel's vector "
+                            "instructions are of the half-rate class -- min/max, compares, selects, rotates -- which cannot reach it: "
+                            "profiles/round2_valu_instruction_classes_mi355x.txt).  l1_addr: wavefront load instructions x 16 cycles / (256 CUs x "
+                            "kernel cycles), what the loads alone take of each CU's one L1 address unit (16 cycles per load instruction whatever "
+                            "the number of active lanes, tools/l1_rate.hip); l1_addr_busy_frac = TA_BUSY_avr / kernel cycles is that unit's own "
+                            "busy counter.  hbm: HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) / kernel time over 8 TB/s.  lane_util_hw = "
+                            "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) is the share of lanes that work in an issued vector "
+                            "instruction.  algorithmic_GBps is served by the caches and is not a fraction of any peak.")
         else:
             roof.update({"bound": "issue", "achieved": None, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,
                          "traffic": None, "note": "this scene / frame size has no committed PMC profile (profiles/pmc_per_launch.json)"})

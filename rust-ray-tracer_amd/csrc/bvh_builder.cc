@@ -14,7 +14,10 @@
 namespace rrt {
 namespace {
 
-constexpr int kBins = 16;
+#ifndef RRT_SAH_BINS
+#define RRT_SAH_BINS 16
+#endif
+constexpr int kBins = RRT_SAH_BINS;
 // experiment knobs (read once): RRT_LEAF_TRIS, RRT_SAH_TCOST
 static uint32_t env_u32(const char* name, uint32_t def, uint32_t lo, uint32_t hi) {
     const char* e = std::getenv(name);
