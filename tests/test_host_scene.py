@@ -28,6 +28,32 @@ def test_instanced_prim_ids_are_in_world_order(rrt, oracle):
     assert s.check().prim_count == o.prim_count
 
 
+def test_the_scaled_box_arithmetic_is_chosen_only_where_it_is_valid(rrt):
+    """rrt_render walks a scene with the scaled form of the box arithmetic (plane indices as denormal floats on a
+    scaled t axis) only if the scene is walked on one grid, the grid's steps are of one order of magnitude, the scene's
+    extent leaves the scale a normal float and the camera's ray directions are of ordinary length; the upload (and this
+    dry run of it) reports the choice."""
+    def soup(scale, cam_len, flat=False):
+        g = np.random.default_rng(5)
+        tris = (g.uniform(-1, 1, (300, 1, 3)) + g.normal(0, 0.05, (300, 3, 3))) * scale
+        if flat:
+            tris[..., 1] = 0.0
+        s = rrt.Scene()
+        s.add_triangles(tris.astype(np.float32), s.add_material(rrt.Lambertian(0.5, 0.5, 0.5)))
+        s.camera = rrt.Camera(1.0, 40.0, np.float32([[cam_len, 0, 0, 0], [0, cam_len, 0, 0], [0, 0, cam_len, 3 * scale]]))
+        return s
+
+    assert soup(1.0, 1.0).check().scaled_slab == 1
+    assert soup(1e-3, 1.0).check().scaled_slab == 1 and soup(1e4, 1.0).check().scaled_slab == 1
+    assert soup(1.0, 1.0, flat=True).check().scaled_slab == 1  # a flat axis still has the builder's pad for an extent
+    assert soup(1.0, 1e-6).check().scaled_slab == 1 and soup(1.0, 1e6).check().scaled_slab == 1
+    assert soup(1.0, 1e-9).check().scaled_slab == 0 and soup(1.0, 1e9).check().scaled_slab == 0  # ray directions too short / long
+    assert soup(1e13, 1.0).check().scaled_slab == 0  # extent above 2^36 (a triangle's box is never thinner than 2e-4)
+    # two-level walk (meshes that hold a sphere or rectangles): one grid per mesh, convert form
+    assert helpers.scene_instanced(rrt).check().scaled_slab == 0 and helpers.scene_cornell(rrt).check().scaled_slab == 0
+    assert helpers.scene_instanced_tris(rrt).check().scaled_slab == 1  # unrolled instances: one grid
+
+
 def test_degenerate_scenes_build(rrt):
     s = rrt.Scene()
     s.add_material(rrt.Lambertian(0.5, 0.5, 0.5))
