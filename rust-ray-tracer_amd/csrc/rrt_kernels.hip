@@ -489,6 +489,9 @@ __global__ __launch_bounds__(WAVE) void k_intersect(SceneDev S, const rrt_ray* _
 // the render kernel: with the whole 39-entry stack in LDS a CU held four workgroups, and the walk is a chain of
 // dependent loads that four wavefronts per SIMD do not cover (tile-ordered primary rays of the 1M-triangle scene:
 // 10.3 Grays/s at four wavefronts, 12.6 at seven; 134M-ray batches, where the tail no longer shows: 14.2).
+#ifndef RRT_STREAM_STEPS
+#define RRT_STREAM_STEPS 5  // node steps between two continuation votes of a node pass, streaming kernel
+#endif
 #ifndef RRT_STREAM_K
 #define RRT_STREAM_K 16
 #endif
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_STREAM_W
         const uint32_t n_walk = 64u - n_idle;
         const uint32_t n_desc = (uint32_t)__popcll(__ballot(T.cur >= 0 || (INST && trav_due(T.cur))));
         const uint32_t share = (n_walk * node_share_64ths) >> 6;
-        if (n_desc >= share) trav_nodes<MODE, COUNT, K, 3>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+        if (n_desc >= share) trav_nodes<MODE, COUNT, K, RRT_STREAM_STEPS>(S, o, d, tmin, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
         if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, tmin, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
     }
     if (COUNT) {
