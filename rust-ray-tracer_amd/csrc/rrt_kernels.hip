@@ -22,6 +22,10 @@
 namespace rrt {
 
 static constexpr int WAVE = 64;
+#ifndef RRT_TILE_W_LOG2
+#define RRT_TILE_W_LOG2 3  // a work item's 64 pixels form a tile of 2^RRT_TILE_W_LOG2 pixels' width (8x8 by default)
+#endif
+static constexpr uint32_t TILE_W = 1u << RRT_TILE_W_LOG2, TILE_H = 64u / TILE_W;
 static constexpr int RENDER_BLOCK = 256;  // 4 independent wavefronts per workgroup
 static constexpr uint32_t TRACE_BLOCK = 512;  // ray indices a wavefront of the streaming kernel draws at a time
 static constexpr int RENDER_STACK = 16;   // traversal stack entries per lane the render kernel keeps in LDS (short stack)
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
             const uint32_t tile = work / G.n_chunks, chunk = work % G.n_chunks;
             uint32_t tx, ty;
             tile_coords(G, tile, tx, ty);
-            const uint32_t x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+            const uint32_t x = tx * TILE_W + (lane & (TILE_W - 1u)), y = ty * TILE_H + (lane >> RRT_TILE_W_LOG2);
             const bool inside = x < width && y < height;
             // samples [first, first + spp) of this chunk, as absolute sample indices
             const uint32_t first = chunk * G.chunk_spp;
@@ -267,8 +271,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 const uint32_t first = chunk * G.chunk_spp;  // samples [first, first + n_spp) as absolute sample indices
                 uint32_t tx, ty;
                 tile_coords(G, tile, tx, ty);
-                x0 = tx * 8u;
-                y0 = ty * 8u;
+                x0 = tx * TILE_W;
+                y0 = ty * TILE_H;
                 n_spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
                 first_sample = G.spp_offset + first;
             }
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                     }
                     if (take) {
                         const uint32_t* rec = items + (stage == 0u ? cur_slot : cur_slot ^ 1u) * 8u;
-                        const uint32_t px_x = rec[0] + (lane & 7u), px_y = rec[1] + (lane >> 3);
+                        const uint32_t px_x = rec[0] + (lane & (TILE_W - 1u)), px_y = rec[1] + (lane >> RRT_TILE_W_LOG2);
                         const uint32_t n_spp = rec[3];
                         if (px_x < width && px_y < height && n_spp != 0u) {
                             xy = px_x | (px_y << 16);
@@ -661,7 +665,7 @@ uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t s
     // tile over many CUs; small frames get more, smaller items so that every resident wave finds a few
     // (target: 4 items per wavefront slot of the chip, 256 CUs x 20 wavefronts).  Never fewer than 4
     // samples per item, never more than 32 partial images.
-    const uint64_t n_tiles = (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u);
+    const uint64_t n_tiles = (uint64_t)((width + TILE_W - 1u) / TILE_W) * ((height + TILE_H - 1u) / TILE_H);
     if (samples_per_item == 0u) samples_per_item = 16u;
     uint64_t n = (spp + samples_per_item - 1u) / samples_per_item;
     const uint64_t for_balance = (4ull * 256ull * 20ull + n_tiles - 1u) / n_tiles;
@@ -702,10 +706,10 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
                          hipStream_t stream) {
     RenderGeom G;
     G.width = width; G.height = height; G.spp = spp; G.spp_offset = spp_offset;
-    G.tiles_x = (width + 7u) / 8u;
-    G.n_tiles = G.tiles_x * ((height + 7u) / 8u);
+    G.tiles_x = (width + TILE_W - 1u) / TILE_W;
+    G.n_tiles = G.tiles_x * ((height + TILE_H - 1u) / TILE_H);
     G.band_tiles = tuning.band_tiles == 0u ? G.tiles_x : std::min(tuning.band_tiles, G.tiles_x);
-    G.band_items = G.band_tiles * ((height + 7u) / 8u);
+    G.band_items = G.band_tiles * ((height + TILE_H - 1u) / TILE_H);
     G.full_bands = G.tiles_x / G.band_tiles;
     G.n_chunks = n_chunks;
     G.chunk_spp = (spp + n_chunks - 1u) / n_chunks;
