@@ -483,7 +483,13 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // Scenes with a real hierarchy (>= 4096 nodes): paths bounce and walks are long, so items of 8 samples, the
     // straggler rule and lanes that move on to the next item by themselves pay; on tiny scenes each of them costs.
     const bool big_scene = c->info.node_count >= 4096u;
-    uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? 8u : 16u);
+    // (large scenes: items of 16 samples on frames of 4K and more from 64 samples per pixel on -- measured on the
+    // 1M-triangle scene at 4K, 128 spp in 8 / 16 chunks 157.3 / 158.3 ms, 256 spp in 16 / 32 chunks 307.4 / 313.9 ms: the
+    // lanes of an item finish closer together the more samples their pixels hold -- and of 8 otherwise: a smaller frame
+    // has fewer tiles to go round and gains more from spreading its expensive ones, 2560x1440 x 128 spp of the
+    // MetalRoughSpheres scene 49.9 ms in 16 chunks against 51.1 ms in 8)
+    const bool many_tiles = (uint64_t)width * height >= 6000000ull;
+    uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? (spp >= 64u && many_tiles ? 16u : 8u) : 16u);
     if (const char* e = std::getenv("RRT_CHUNKS")) {
         const int v = std::atoi(e);
         if (v >= 1) n_chunks = std::min<uint32_t>((uint32_t)v, spp);
