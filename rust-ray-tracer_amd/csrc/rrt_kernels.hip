@@ -70,6 +70,12 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_UNROLLED_WAVES
 #define RRT_UNROLLED_WAVES 7  // workgroups per CU the pipelined form is compiled for on unrolled scenes
 #endif
+#ifndef RRT_WALK_PRIO
+#define RRT_WALK_PRIO 0  // wavefront priority during the walk phase of the pipelined form (0: none set)
+#endif
+#ifndef RRT_SHADE_PRIO
+#define RRT_SHADE_PRIO 0  // ... and during the shade phase
+#endif
 #ifndef RRT_FLAT_WAVES
 #define RRT_FLAT_WAVES 7  // workgroups per CU the pipelined form is compiled for on scenes without instances
 #endif
@@ -315,6 +321,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
             }
             if (out_of_work) break;
 
+#if RRT_WALK_PRIO || RRT_SHADE_PRIO
+            __builtin_amdgcn_s_setprio(RRT_WALK_PRIO);
+#endif
             // ---- walk phase: node passes and leaf passes alternate until every lane's walk is complete.
             // A pass costs the same however many lanes take part, so a node pass only runs (and only keeps
             // running) while a fair share of the walking lanes is descending; below that share the lanes
@@ -347,6 +356,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
             }
 
+#if RRT_WALK_PRIO || RRT_SHADE_PRIO
+            __builtin_amdgcn_s_setprio(RRT_SHADE_PRIO);
+#endif
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
             // next sample, a lane whose item ended (or that has none yet) takes its pixel of the item it is due for
             const bool shade_now = has_ray && T.cur == REF_DONE;
