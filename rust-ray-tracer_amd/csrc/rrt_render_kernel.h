@@ -69,6 +69,12 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_SHADE_PRIO
 #define RRT_SHADE_PRIO 0  // ... and during the shade phase
 #endif
+#ifndef RRT_LANE_FLIP
+#define RRT_LANE_FLIP 63  // pipelined form: lane l takes pixel l ^ RRT_LANE_FLIP of the tile in every second item (0: always pixel l)
+#endif
+#ifndef RRT_ITEM_RING
+#define RRT_ITEM_RING 2  // pipelined form: work items a wavefront holds at a time (2 or 3)
+#endif
 #ifndef RRT_FLAT_WAVES
 #define RRT_FLAT_WAVES 7  // workgroups per CU the pipelined form is compiled for on scenes without instances
 #endif
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
     constexpr int K = INST ? RRT_INST_STACK : RENDER_STACK;
     __shared__ int s_stack[K * RENDER_BLOCK];
     __shared__ float s_wray[INST ? 6 * RENDER_BLOCK : 1];
-    __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 16];  // per wavefront: the records of its two work items
+    __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 8 * RRT_ITEM_RING];  // per wavefront: the records of its work items in flight
     // Unrolled scenes: the instance transforms a triangle leaf needs (offset, sin, cos: the first 32 bytes of a record)
     // are copied to LDS once per workgroup when they fit, slot 0 = the identity record in front of the table.
     __shared__ vec4f s_xf[MODE == MODE_UNROLLED ? 2 * XF_LDS_SLOTS : 1];
@@ -258,9 +264,16 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
         // whatever the interleaving, so the image does not depend on it.
         // The two items' records live in LDS (x0, y0, chunk, sample count, first sample index; count 0 = no item): a
         // lane reads the one it moves to, the wave writes one when it draws an item.
-        uint32_t* items = s_items + (threadIdx.x >> 6) * 16u;
-        uint32_t cur_slot = 0u;    // record of the current item; the next item's is the other one
-        bool next_valid = false;
+        constexpr uint32_t RING = RRT_ITEM_RING;
+        static_assert(RING >= 2u && RING <= 3u, "two or three items in flight");
+        uint32_t* items = s_items + (threadIdx.x >> 6) * (8u * RING);
+        uint32_t cur_slot = 0u;    // record of the current item; the item p places ahead has record (cur_slot + p) % RING
+        uint32_t ahead_valid = 0u; // items behind the current one that exist (they are drawn in order: a prefix of the ring)
+        uint32_t flip = 0u;        // alternates from item to item: which pixel of the tile a lane takes (RRT_LANE_FLIP)
+        auto slot_of = [&](uint32_t pos) -> uint32_t {
+            const uint32_t t = cur_slot + pos;
+            return t >= RING ? t - RING : t;
+        };
         auto draw_into = [&](uint32_t slot) -> bool {
             const uint32_t work = draw();
             uint32_t x0 = 0u, y0 = 0u, chunk = 0u, n_spp = 0u, first_sample = 0u;
@@ -277,15 +290,16 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
             }
             if (lane == 0u) {
                 uint32_t* rec = items + slot * 8u;
-                rec[0] = x0; rec[1] = y0; rec[2] = chunk; rec[3] = n_spp; rec[4] = first_sample;
+                rec[0] = x0; rec[1] = y0; rec[2] = chunk; rec[3] = n_spp; rec[4] = first_sample; rec[5] = flip;
             }
+            flip ^= (uint32_t)RRT_LANE_FLIP;
             return work != NO_WORK;
         };
         draw_into(0u);
-        next_valid = draw_into(1u);
+        for (uint32_t p = 1u; p < RING; ++p) ahead_valid += draw_into(p) ? 1u : 0u;
 
-        // per lane: `stage` = which of the two items it is on (0: current, 1: next, 2: done with both), + 4 once it
-        // has taken its pixel of that item; then its place in the item
+        // per lane: `stage` = which of the items in flight it is on (0: current, 1: next, ..., RING: done with all),
+        // + 4 once it has taken its pixel of that item; then its place in the item
         uint32_t stage = 0u;
         // (kept small: the kernel runs at the register budget of six waves per SIMD)
         uint32_t xy = 0;           // the lane's pixel, x | y << 16
@@ -304,13 +318,14 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
             // ---- item rotation (touches nothing of a lane but its stage)
             bool out_of_work = false;
             while (__ballot((stage & 3u) == 0u) == 0ull) {
-                if (!next_valid) {
+                if (ahead_valid == 0u) {
                     out_of_work = true;  // nobody on the current item and no next item: every lane is done
                     break;
                 }
                 stage--;
-                next_valid = draw_into(cur_slot);  // the old current item's record is free
-                cur_slot ^= 1u;
+                const bool drew = draw_into(cur_slot);  // the old current item's record is free: it becomes the last one's
+                ahead_valid = ahead_valid - 1u + (drew ? 1u : 0u);
+                cur_slot = slot_of(1u);
             }
             if (out_of_work) break;
 
@@ -338,10 +353,22 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         trav_nodes<MODE, COUNT, K, RRT_PIPE_STEPS, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
+#ifdef RRT_COUNT_NORAY  // experiment: the second idle counter counts the lanes that have no ray at all instead
+#if RRT_COUNT_NORAY == 2  // ... only those that could take a pixel of an item in flight and wait for the next shading pass to do it
+                        const uint32_t n_noray = (uint32_t)__popcll(__ballot(!has_ray && stage < RING));
+#else
+                        const uint32_t n_noray = (uint32_t)__popcll(__ballot(!has_ray));
+#endif
+                        if (lane == 0u) {
+                            slots_done += (unsigned long long)steps * (64u - n_walk);
+                            slots_leaf += (unsigned long long)steps * n_noray;
+                        }
+#else
                         if (lane == 0u) {
                             slots_done += (unsigned long long)steps * (64u - n_walk);
                             slots_leaf += (unsigned long long)steps * (n_walk - n_desc);
                         }
+#endif
                     } else {
                         trav_nodes<MODE, COUNT, K, RRT_PIPE_STEPS, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                     }
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
             // next sample, a lane whose item ended (or that has none yet) takes its pixel of the item it is due for
             const bool shade_now = has_ray && T.cur == REF_DONE;
-            bool take = stage == 0u || stage == 1u;  // on an item without having taken its pixel of it
+            bool take = stage < RING;  // on an item without having taken its pixel of it
             if (shade_now || take) {
                 bool alive = false;
                 V3 radiance = v3(0.f, 0.f, 0.f);  // what the path emits: one term, at its last surface (see above)
@@ -378,19 +405,23 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         left--;
                         if (left == 0u) {  // this lane's part of the item is complete: one 12-byte store
                             const uint32_t on = stage & 3u;
-                            const uint32_t chunk = items[(on == 0u ? cur_slot : cur_slot ^ 1u) * 8u + 2u];
+                            const uint32_t chunk = items[slot_of(on) * 8u + 2u];
                             const uint32_t pixel = (xy >> 16) * width + (xy & 0xFFFFu);
                             float* px = out + 3ull * ((size_t)chunk * width * height + pixel);
                             px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
                             has_ray = false;
                             start = false;
                             stage = on + 1u;
-                            take = stage == 1u;
+                            take = stage < RING;
                         }
                     }
                     if (take) {
-                        const uint32_t* rec = items + (stage == 0u ? cur_slot : cur_slot ^ 1u) * 8u;
-                        const uint32_t px_x = rec[0] + (lane & (TILE_W - 1u)), px_y = rec[1] + (lane >> RRT_TILE_W_LOG2);
+                        const uint32_t* rec = items + slot_of(stage) * 8u;
+                        // which pixel of the tile the lane takes: mirrored (RRT_LANE_FLIP) in every second item of the
+                        // wavefront, so that a lane whose pixel was cheap in one item (sky above a horizon, say) gets
+                        // the opposite corner of the tile in the next
+                        const uint32_t pl = lane ^ rec[5];
+                        const uint32_t px_x = rec[0] + (pl & (TILE_W - 1u)), px_y = rec[1] + (pl >> RRT_TILE_W_LOG2);
                         const uint32_t n_spp = rec[3];
                         if (px_x < width && px_y < height && n_spp != 0u) {
                             xy = px_x | (px_y << 16);
