@@ -2,6 +2,19 @@
 // Included by the two translation units that instantiate it: rrt_kernels.hip (scenes without instances, two-level
 // walk) and rrt_kernels_unrolled.hip (unrolled instances), which are compiled with different scheduling strategies
 // (the Makefile says which and why).
+//
+// k_render is a persistent-wavefront kernel: the grid is sized to what the chip holds at once, and every
+// 64-lane wavefront pulls work items from eight queues (one per group of workgroups that share an XCD).
+// A work item is (8x8 pixel tile, chunk of samples).  Inside an item one lane owns one pixel and runs the
+// reference's per-pixel loop (src/main.rs:87-103) flattened over (sample, bounce): every loop trip
+// traces exactly one ray, and a lane whose path ended starts its next sample at once, so lanes are never
+// parked waiting for the longest path in the wave.  The radiance sum stays in registers and is written
+// once per item (12 bytes per pixel).  Traversal stacks live in LDS (STACK_DEPTH dwords per lane, laid
+// out [entry][thread] so that a wave access touches 64 consecutive banks).
+// The kernel has two forms of the loop over items (template parameter PIPELINED): one item at a time, or two
+// items in flight per wavefront with every lane moving from one to the next by itself.  The two forms are kept as
+// separate texts on purpose: written over shared helpers the pipelined form compiled to 3-20 % slower code
+// (register allocation at the 128-VGPR limit of four waves per SIMD).
 #ifndef RRT_RENDER_KERNEL_H
 #define RRT_RENDER_KERNEL_H
 
