@@ -34,7 +34,10 @@ static constexpr int WAVE = 64;
 static constexpr uint32_t TILE_W = 1u << RRT_TILE_W_LOG2, TILE_H = 64u / TILE_W;
 static constexpr int RENDER_BLOCK = 256;  // 4 independent wavefronts per workgroup
 static constexpr uint32_t TRACE_BLOCK = 512;  // ray indices a wavefront of the streaming kernel draws at a time
-static constexpr int RENDER_STACK = 16;   // traversal stack entries per lane the render kernel keeps in LDS (short stack)
+#ifndef RRT_RENDER_STACK
+#define RRT_RENDER_STACK 16
+#endif
+static constexpr int RENDER_STACK = RRT_RENDER_STACK;   // traversal stack entries per lane the render kernel keeps in LDS (short stack)
 // (With 20 the private remainder is 19 entries, small enough for the compiler to turn it into registers: the one-item
 // form then spills 95 of them and runs eight times slower.  Larger LDS parts bought nothing anyway: walks seldom
 // leave the first 16 entries.)
