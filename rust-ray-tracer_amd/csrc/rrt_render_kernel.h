@@ -73,6 +73,9 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_PIPE_STEPS
 #define RRT_PIPE_STEPS 5  // node steps between two continuation votes of a node pass, pipelined form
 #endif
+#ifndef RRT_UNROLLED_STEPS
+#define RRT_UNROLLED_STEPS 6  // ... of the pipelined form on unrolled scenes (measured: 4 / 5 / 6 / 7 / 8 -> 168.4 / 168.7 / 163.3 / 165.3 / 168.7 ms)
+#endif
 #ifndef RRT_ONE_STEPS
 #define RRT_ONE_STEPS 2  // ... and in the one-item form
 #endif
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<MODE, COUNT, K, RRT_PIPE_STEPS, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, (MODE == MODE_UNROLLED ? RRT_UNROLLED_STEPS : RRT_PIPE_STEPS), SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
 #ifdef RRT_COUNT_NORAY  // experiment: the second idle counter counts the lanes that have no ray at all instead
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         }
 #endif
                     } else {
-                        trav_nodes<MODE, COUNT, K, RRT_PIPE_STEPS, SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, (MODE == MODE_UNROLLED ? RRT_UNROLLED_STEPS : RRT_PIPE_STEPS), SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                     }
                 }
                 if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
