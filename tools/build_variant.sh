@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../rust-ray-tracer_amd"
 NAME=$1; shift
 mkdir -p exp_libs
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -fno-slp-vectorize"
+BASE="--offload-arch=gfx950 ${OPT:--O3} -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -fno-slp-vectorize"
 if [ -z "$UNROLLED_ONLY" ]; then
     /opt/rocm/bin/hipcc $BASE -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c csrc/rrt_kernels.hip -o exp_libs/$NAME.o
     K1=exp_libs/$NAME.o
