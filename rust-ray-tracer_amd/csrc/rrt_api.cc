@@ -531,7 +531,13 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
         tuning.leave_walk = 0u;
         tuning.overlap_items = 0u;
         tuning.band_tiles = 0u;
-    } else if (c->info.node_count >= (1u << 21)) {
+    } else {
+        // bands a fifteenth of the frame wide, 16 to 64 tiles (measured on MI355X: at 8K bands of 64 tiles instead of 16
+        // render the unrolled 10M-triangle scene in 159.9 instead of 162.8 ms and the flat one in 165.0 instead of 169.3;
+        // at 4K 16 / 32 / 64 tiles are within 0.3 % of each other, at 2560x1440 64 cost 1 %)
+        tuning.band_tiles = std::min(64u, std::max(16u, ((width + 7u) / 8u) / 15u));
+    }
+    if (big_scene && c->info.node_count >= (1u << 21)) {
         // the walks of multi-million-node scenes have longer tails: more stragglers are left behind per trip
         // (measured on MI355X, ten million triangles: 12 -> 20 is 1-2 % faster, flat and unrolled alike)
         tuning.leave_walk = 20u;
