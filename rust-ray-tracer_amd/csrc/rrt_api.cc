@@ -488,8 +488,14 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // lanes of an item finish closer together the more samples their pixels hold -- and of 8 otherwise: a smaller frame
     // has fewer tiles to go round and gains more from spreading its expensive ones, 2560x1440 x 128 spp of the
     // MetalRoughSpheres scene 49.9 ms in 16 chunks against 51.1 ms in 8)
-    const bool many_tiles = (uint64_t)width * height >= 6000000ull;
-    uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? (spp >= 64u && many_tiles ? 16u : 8u) : 16u);
+    // (at 8K, four times the tiles again: items of 32 samples from 128 spp on, 256 spp of the unrolled 10M-triangle scene in
+    // 8 / 16 / 32 chunks 2350 / 2385 / 2478 ms)
+    const uint64_t pixels = (uint64_t)width * height;
+    const bool many_tiles = pixels >= 6000000ull;
+    uint32_t per_item = 8u;
+    if (spp >= 64u && many_tiles) per_item = 16u;
+    if (spp >= 128u && pixels >= 24000000ull) per_item = 32u;
+    uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? per_item : 16u);
     if (const char* e = std::getenv("RRT_CHUNKS")) {
         const int v = std::atoi(e);
         if (v >= 1) n_chunks = std::min<uint32_t>((uint32_t)v, spp);
