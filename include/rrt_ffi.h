@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 1u
+#define RRT_ABI_VERSION 2u  /* 2: rrt_scene_info grew by scaled_slab, reserved */
 
 typedef enum rrt_status {
     RRT_OK = 0,

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(rrt):
     lib = rrt.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), f"librrt_hip.so does not export {name}"
-    assert lib.rrt_abi_version() == 1
+    assert lib.rrt_abi_version() == 2
 
 
 def test_header_compiles_as_c_and_pod_sizes_match(rrt, tmp_path):
