@@ -538,10 +538,10 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
         tuning.overlap_items = 0u;
         tuning.band_tiles = 0u;
     } else {
-        // bands a fifteenth of the frame wide, 16 to 64 tiles (measured on MI355X: at 8K bands of 64 tiles instead of 16
-        // render the unrolled 10M-triangle scene in 159.9 instead of 162.8 ms and the flat one in 165.0 instead of 169.3;
-        // at 4K 16 / 32 / 64 tiles are within 0.3 % of each other, at 2560x1440 64 cost 1 %)
-        tuning.band_tiles = std::min(64u, std::max(16u, ((width + 7u) / 8u) / 15u));
+        // bands of 64 tiles instead of 16 on frames of 8K width (measured on MI355X: the unrolled 10M-triangle scene in 159.9
+        // instead of 162.8 ms, the flat one in 165.0 instead of 169.3; at 4K x 1024 spp 16 / 32 / 64 tiles take 1174 / 1182 /
+        // 1195 ms, at 2560x1440 64 cost 1 %)
+        if (width >= 7000u) tuning.band_tiles = 64u;
     }
     if (big_scene && c->info.node_count >= (1u << 21)) {
         // the walks of multi-million-node scenes have longer tails: more stragglers are left behind per trip
