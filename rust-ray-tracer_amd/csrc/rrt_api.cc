@@ -483,18 +483,15 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // Scenes with a real hierarchy (>= 4096 nodes): paths bounce and walks are long, so items of 8 samples, the
     // straggler rule and lanes that move on to the next item by themselves pay; on tiny scenes each of them costs.
     const bool big_scene = c->info.node_count >= 4096u;
-    // (large scenes: items of 16 samples on frames of 4K and more from 64 samples per pixel on -- measured on the
-    // 1M-triangle scene at 4K, 128 spp in 8 / 16 chunks 157.3 / 158.3 ms, 256 spp in 16 / 32 chunks 307.4 / 313.9 ms: the
-    // lanes of an item finish closer together the more samples their pixels hold -- and of 8 otherwise: a smaller frame
-    // has fewer tiles to go round and gains more from spreading its expensive ones, 2560x1440 x 128 spp of the
-    // MetalRoughSpheres scene 49.9 ms in 16 chunks against 51.1 ms in 8)
-    // (at 8K, four times the tiles again: items of 32 samples from 128 spp on, 256 spp of the unrolled 10M-triangle scene in
-    // 8 / 16 / 32 chunks 2350 / 2385 / 2478 ms)
+    // Multi-million-node scenes (fetch-bound: more than the caches hold) keep items of 64 pixels x one chunk and get
+    // larger chunks on large frames (measured on the unrolled 10M-triangle scene at 8K: 256 spp in 8 / 16 / 32 chunks
+    // 2350 / 2385 / 2478 ms; items of a few pixels x many chunks: 2376 ms, and 165.7 against 160.0 ms at 16 spp); other
+    // large scenes get chunks of 8 samples, which their items hold side by side (launch_render).
+    const bool huge_scene = c->info.node_count >= (1u << 21);
     const uint64_t pixels = (uint64_t)width * height;
-    const bool many_tiles = pixels >= 6000000ull;
     uint32_t per_item = 8u;
-    if (spp >= 64u && many_tiles) per_item = 16u;
-    if (spp >= 128u && pixels >= 24000000ull) per_item = 32u;
+    if (huge_scene && spp >= 64u && pixels >= 6000000ull) per_item = 16u;
+    if (huge_scene && spp >= 128u && pixels >= 24000000ull) per_item = 32u;
     uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? per_item : 16u);
     if (const char* e = std::getenv("RRT_CHUNKS")) {
         const int v = std::atoi(e);
@@ -543,7 +540,8 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
         // 1195 ms, at 2560x1440 64 cost 1 %)
         if (width >= 7000u) tuning.band_tiles = 64u;
     }
-    if (big_scene && c->info.node_count >= (1u << 21)) {
+    tuning.split_items = big_scene && !huge_scene ? 1u : 0u;
+    if (big_scene && huge_scene) {
         // the walks of multi-million-node scenes have longer tails: more stragglers are left behind per trip
         // (measured on MI355X, ten million triangles: 12 -> 20 is 1-2 % faster, flat and unrolled alike)
         tuning.leave_walk = 20u;
@@ -553,6 +551,7 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     if (const char* e = std::getenv("RRT_OVERLAP_ITEMS")) tuning.overlap_items = std::atoi(e) != 0 ? 1u : 0u;
     if (const char* e = std::getenv("RRT_BAND_TILES")) tuning.band_tiles = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RRT_SCALED_SLAB")) tuning.scaled_slab = std::atoi(e) != 0 ? 1u : 0u;
+    if (const char* e = std::getenv("RRT_SPLIT_ITEMS")) tuning.split_items = std::atoi(e) != 0 ? 1u : 0u;
     if (rrt_status st = order_after_pending(c, s)) return st;
     RRT_HIP(c, hipMemsetAsync(d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));

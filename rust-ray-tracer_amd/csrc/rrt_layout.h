@@ -181,6 +181,8 @@ struct RenderGeom {
     uint32_t node_share_64ths;  // a node pass runs while at least this share (in 64ths) of the walking lanes descends
     uint32_t leave_walk;        // a trip's walk phase ends when at most this many lanes still walk ...
     uint32_t leave_ready;       // ... and at least this many lanes wait to shade (leave_walk 0: walk to the end)
+    uint32_t n_groups;          // work items per tile (pipelined form: an item holds several consecutive chunks of its pixels)
+    uint32_t pix_log2, tw_log2; // pipelined form: an item is 2^pix_log2 pixels (a tile 2^tw_log2 pixels wide) x 64 / pixels chunks
 };
 
 // Per-lane traversal stack entries (LDS).  One inner-node step pushes at most one entry, so the stack never

@@ -32,6 +32,9 @@ static constexpr int WAVE = 64;
 #define RRT_TILE_W_LOG2 3  // a work item's 64 pixels form a tile of 2^RRT_TILE_W_LOG2 pixels' width (8x8 by default)
 #endif
 static constexpr uint32_t TILE_W = 1u << RRT_TILE_W_LOG2, TILE_H = 64u / TILE_W;
+// Pipelined form: the 64 lanes of a work item are 2^G.pix_log2 pixels (a tile of 2^G.tw_log2 pixels' width) times
+// 64 / pixels consecutive sample chunks of each pixel; the launcher picks the split (launch_render).  RRT_PIPE_PIX_LOG2
+// (build knob, 1 .. 6) fixes it instead.
 static constexpr int RENDER_BLOCK = 256;  // 4 independent wavefronts per workgroup
 static constexpr uint32_t TRACE_BLOCK = 512;  // ray indices a wavefront of the streaming kernel draws at a time
 #ifndef RRT_RENDER_STACK
@@ -102,7 +105,10 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #endif
 // SCALED: the node steps use the scaled form of the slab arithmetic (rrt_device.h: trav_set_ray_scaled), which the host
 // selects when the scene is walked on one grid and its camera's ray directions are of ordinary magnitude.
-template <int MODE, bool COUNT, bool PIPELINED, bool SCALED>
+// SPLIT (pipelined form, scenes without instances): an item's 64 lanes are G.pix_log2 pixels times several of their
+// sample chunks instead of 64 pixels times one (launch_render picks the split); a template parameter because the
+// general index arithmetic costs the other scenes 1-3 % when it is merely switched off at run time.
+template <int MODE, bool COUNT, bool PIPELINED, bool SCALED, bool SPLIT = false>
 __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? RRT_UNROLLED_WAVES : RRT_FLAT_WAVES) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
@@ -283,6 +289,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
         // whatever the interleaving, so the image does not depend on it.
         // The two items' records live in LDS (x0, y0, chunk, sample count, first sample index; count 0 = no item): a
         // lane reads the one it moves to, the wave writes one when it draws an item.
+        [[maybe_unused]] const uint32_t pix_log2 = SPLIT ? G.pix_log2 : 6u, tw_log2 = SPLIT ? G.tw_log2 : (uint32_t)RRT_TILE_W_LOG2;
         constexpr uint32_t RING = RRT_ITEM_RING;
         static_assert(RING >= 2u && RING <= 3u, "two or three items in flight");
         uint32_t* items = s_items + (threadIdx.x >> 6) * (8u * RING);
@@ -295,21 +302,39 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
         };
         auto draw_into = [&](uint32_t slot) -> bool {
             const uint32_t work = draw();
+            // record: x0, y0, first chunk, samples of a full chunk (one chunk per item: of this chunk), first sample
+            // index of the first chunk, pixel permutation, chunks of the item that exist, samples of the last of them
             uint32_t x0 = 0u, y0 = 0u, chunk = 0u, n_spp = 0u, first_sample = 0u;
+            [[maybe_unused]] uint32_t n_valid = 0u, n_last = 0u;
             if (work != NO_WORK) {
-                const uint32_t tile = work / G.n_chunks;
-                chunk = work % G.n_chunks;
-                const uint32_t first = chunk * G.chunk_spp;  // samples [first, first + n_spp) as absolute sample indices
-                uint32_t tx, ty;
-                tile_coords(G, tile, tx, ty);
-                x0 = tx * TILE_W;
-                y0 = ty * TILE_H;
-                n_spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
-                first_sample = G.spp_offset + first;
+                if constexpr (SPLIT) {
+                    const uint32_t tile = work / G.n_groups;
+                    chunk = (work % G.n_groups) << (6u - pix_log2);  // the item's first chunk; lane group s renders chunk + s
+                    uint32_t tx, ty;
+                    tile_coords(G, tile, tx, ty);
+                    x0 = tx << tw_log2;
+                    y0 = ty << (pix_log2 - tw_log2);
+                    n_spp = G.chunk_spp;
+                    first_sample = G.spp_offset + chunk * G.chunk_spp;
+                    n_valid = min(64u >> pix_log2, G.n_chunks - chunk);
+                    const uint32_t last_first = (chunk + n_valid - 1u) * G.chunk_spp;
+                    n_last = last_first < G.spp ? min(G.chunk_spp, G.spp - last_first) : 0u;
+                } else {
+                    const uint32_t tile = work / G.n_chunks;
+                    chunk = work % G.n_chunks;
+                    const uint32_t first = chunk * G.chunk_spp;  // samples [first, first + n_spp) as absolute sample indices
+                    uint32_t tx, ty;
+                    tile_coords(G, tile, tx, ty);
+                    x0 = tx * TILE_W;
+                    y0 = ty * TILE_H;
+                    n_spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
+                    first_sample = G.spp_offset + first;
+                }
             }
             if (lane == 0u) {
                 uint32_t* rec = items + slot * 8u;
                 rec[0] = x0; rec[1] = y0; rec[2] = chunk; rec[3] = n_spp; rec[4] = first_sample; rec[5] = flip;
+                if constexpr (SPLIT) { rec[6] = n_valid; rec[7] = n_last; }
             }
             flip ^= (uint32_t)RRT_LANE_FLIP;
             return work != NO_WORK;
@@ -424,7 +449,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         left--;
                         if (left == 0u) {  // this lane's part of the item is complete: one 12-byte store
                             const uint32_t on = stage & 3u;
-                            const uint32_t chunk = items[slot_of(on) * 8u + 2u];
+                            uint32_t chunk = items[slot_of(on) * 8u + 2u];
+                            if constexpr (SPLIT) chunk += (lane ^ items[slot_of(on) * 8u + 5u]) >> pix_log2;
                             const uint32_t pixel = (xy >> 16) * width + (xy & 0xFFFFu);
                             float* px = out + 3ull * ((size_t)chunk * width * height + pixel);
                             px[0] = sum.x; px[1] = sum.y; px[2] = sum.z;
@@ -440,12 +466,23 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         // wavefront, so that a lane whose pixel was cheap in one item (sky above a horizon, say) gets
                         // the opposite corner of the tile in the next
                         const uint32_t pl = lane ^ rec[5];
-                        const uint32_t px_x = rec[0] + (pl & (TILE_W - 1u)), px_y = rec[1] + (pl >> RRT_TILE_W_LOG2);
-                        const uint32_t n_spp = rec[3];
+                        uint32_t px_x, px_y, n_spp = rec[3];
+                        [[maybe_unused]] uint32_t first_sample = 0u;
+                        if constexpr (SPLIT) {
+                            // the lane's chunk of the pixel: the item's first chunk + the lane's group
+                            const uint32_t pix = pl & ((1u << pix_log2) - 1u), sub = pl >> pix_log2, n_valid = rec[6];
+                            px_x = rec[0] + (pix & ((1u << tw_log2) - 1u));
+                            px_y = rec[1] + (pix >> tw_log2);
+                            first_sample = rec[4] + sub * n_spp;
+                            n_spp = sub + 1u < n_valid ? n_spp : (sub + 1u == n_valid ? rec[7] : 0u);
+                        } else {
+                            px_x = rec[0] + (pl & (TILE_W - 1u));
+                            px_y = rec[1] + (pl >> RRT_TILE_W_LOG2);
+                        }
                         if (px_x < width && px_y < height && n_spp != 0u) {
                             xy = px_x | (px_y << 16);
                             left = n_spp;
-                            next_sample = rec[4];
+                            next_sample = SPLIT ? first_sample : rec[4];
                             sum = v3(0.f, 0.f, 0.f);
                             stage += 4u;
                             start = true;
@@ -487,14 +524,14 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
     if (lane == 0) atomicAdd(&counters[0], rays);
 }
 
-template <int MODE, bool COUNT, bool PIPELINED, bool SCALED = false>
+template <int MODE, bool COUNT, bool PIPELINED, bool SCALED = false, bool SPLIT = false>
 static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, float* out, unsigned long long* d_counters,
                                         unsigned int* d_heads, int cu_count, hipStream_t stream) {
     // persistent grid: as many workgroups as the chip holds at once (never more than there are work items)
     static int blocks_per_cu = 0;  // per template instantiation
     if (blocks_per_cu == 0) {
         int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<MODE, COUNT, PIPELINED, SCALED>, RENDER_BLOCK, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT>, RENDER_BLOCK, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = n > 0 ? n : 1;
         // experiment knob: fewer resident workgroups per CU (occupancy sensitivity)
@@ -507,7 +544,7 @@ static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, 
     const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;
     if (blocks > needed) blocks = needed;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED, SCALED>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
+    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
     return hipGetLastError();
 }
 
