@@ -277,6 +277,12 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
         while (sub_log2 < 5u && (1u << sub_log2) < n_chunks) ++sub_log2;  // chunks per item: the power of two that holds them all, at most 32
         pix_log2 = 6u - sub_log2;
 #endif
+        // the split form takes every chunk but the last as full and the last as not empty (the library's callers see to
+        // that), and its items are numbered with 31 bits like the others: whole tiles otherwise
+        const uint32_t chunk_spp = (spp + n_chunks - 1u) / n_chunks, w_log2 = pix_log2 / 2u, h_log2 = pix_log2 - w_log2;
+        const uint64_t items = (uint64_t)((width + (1u << w_log2) - 1u) >> w_log2) * ((height + (1u << h_log2) - 1u) >> h_log2) *
+                               ((n_chunks + (64u >> pix_log2) - 1u) >> (6u - pix_log2));
+        if ((uint64_t)(n_chunks - 1u) * chunk_spp >= spp || items > 0x7FFFFFFFull) pix_log2 = 6u;
     }
     const uint32_t tw_log2 = pipelined ? (pix_log2 == 6u ? (uint32_t)RRT_TILE_W_LOG2 : pix_log2 / 2u) : (uint32_t)RRT_TILE_W_LOG2;
     const uint32_t tw = 1u << tw_log2, th = (pipelined ? (1u << pix_log2) : 64u) / tw, sub = pipelined ? (64u >> pix_log2) : 1u;
