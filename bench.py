@@ -242,7 +242,9 @@ def main():
     if rank == 0:
         counting = rrt.Renderer(device=gpu_index, seed=args.seed, count_visits=True, device_build=args.device_build)
         counting.upload(scene)
-        probe_spp = min(spp, int(os.environ.get("RRT_PROBE_SPP", "8")))  # samples of the counting launch
+        # samples of the counting launch: enough for the launch to be cut into items the way the timed one is (one GPU's
+        # share of the headline frame under eight-way scaling); a launch of a few samples is one chunk and mostly tail
+        probe_spp = min(spp, int(os.environ.get("RRT_PROBE_SPP", "128")))
         counting.render_device(width, height, probe_spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
         cs = counting.render_stats()
         counting.close()
