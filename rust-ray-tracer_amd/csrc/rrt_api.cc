@@ -492,12 +492,33 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     uint32_t per_item = 8u;
     if (huge_scene && spp >= 64u && pixels >= 6000000ull) per_item = 16u;
     if (huge_scene && spp >= 128u && pixels >= 24000000ull) per_item = 32u;
+    // Items of a few pixels x many of their chunks (launch_render) on every other scene without instances that has
+    // pixels of unequal cost to even out: suzanne 1080p x 256 spp 11.1 -> 10.6 ms, x 1024 spp 32.7 -> 29.9 ms; not on
+    // scenes of a few primitives (12-primitive scene 0.94 -> 1.03 ms with it).  RRT_SPLIT_ITEMS overrides the rule.
+    bool split_items = !huge_scene && c->info.node_count >= 64u;
+    if (const char* e = std::getenv("RRT_SPLIT_ITEMS")) split_items = std::atoi(e) != 0;
     uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? per_item : 16u);
     if (const char* e = std::getenv("RRT_CHUNKS")) {
         const int v = std::atoi(e);
         if (v >= 1) n_chunks = std::min<uint32_t>((uint32_t)v, spp);
     }
     while (n_chunks > 1u && (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * n_chunks > 0x7FFFFFFFull) n_chunks /= 2u;
+    // Split items hold a power of two of chunks side by side (launch_render) and pay only while every lane of an item has
+    // the same number of samples to render: the power of two nearest to the count chosen above (within a factor of two)
+    // that divides the sample count; whole tiles where there is none.  Measured on MI355X, 1M-triangle scene at 4K:
+    // 100 spp as 13 chunks in 16 slots 148.1 ms, as 8 chunks of 13 (the last of 9) 125.1 ms, whole tiles 123.1 ms; 96 spp
+    // as 12 chunks in 16 slots 147.4 ms, as 8 or 16 equal chunks 116.3 ms.  (RRT_CHUNKS is taken as it is.)
+    if (split_items && n_chunks > 1u && !std::getenv("RRT_CHUNKS")) {
+        uint32_t best = 0u;
+        for (uint32_t p = 8u; p <= 32u; p *= 2u) {  // (items of 16 pixels and more are no better than whole tiles)
+            if (spp % p != 0u || p > 2u * n_chunks || n_chunks > 2u * p) continue;
+            // nearer to the chosen count in ratio; of two equally near ones the larger
+            if (best == 0u || (p >= n_chunks ? (uint64_t)p * best <= (uint64_t)n_chunks * n_chunks : true)) best = p;
+        }
+        if (best != 0u) n_chunks = best;
+        else split_items = false;
+    }
+    if (n_chunks <= 1u) split_items = false;
     // No chunk may be empty: a chunk holds ceil(spp / n_chunks) samples, so only ceil(spp / that) chunks have any
     // (50 samples in 12 chunks are 10 chunks of 5), and the kernel writes a partial image only for chunks with samples.
     {
@@ -540,7 +561,7 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
         // 1195 ms, at 2560x1440 64 cost 1 %)
         if (width >= 7000u) tuning.band_tiles = 64u;
     }
-    tuning.split_items = big_scene && !huge_scene ? 1u : 0u;
+    tuning.split_items = split_items ? 1u : 0u;
     if (big_scene && huge_scene) {
         // the walks of multi-million-node scenes have longer tails: more stragglers are left behind per trip
         // (measured on MI355X, ten million triangles: 12 -> 20 is 1-2 % faster, flat and unrolled alike)
@@ -551,7 +572,6 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     if (const char* e = std::getenv("RRT_OVERLAP_ITEMS")) tuning.overlap_items = std::atoi(e) != 0 ? 1u : 0u;
     if (const char* e = std::getenv("RRT_BAND_TILES")) tuning.band_tiles = (uint32_t)std::max(0, std::atoi(e));
     if (const char* e = std::getenv("RRT_SCALED_SLAB")) tuning.scaled_slab = std::atoi(e) != 0 ? 1u : 0u;
-    if (const char* e = std::getenv("RRT_SPLIT_ITEMS")) tuning.split_items = std::atoi(e) != 0 ? 1u : 0u;
     if (rrt_status st = order_after_pending(c, s)) return st;
     RRT_HIP(c, hipMemsetAsync(d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));

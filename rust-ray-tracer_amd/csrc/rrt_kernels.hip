@@ -260,7 +260,7 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
                          hipStream_t stream) {
     // the pipelined form packs a lane's pixel coordinates into 16 bits each
     const bool pipelined = tuning.overlap_items != 0u && width < 65536u && height < 65536u;
-    // Pipelined form: an item is a few pixels times as many of their sample chunks as make 64 lanes -- all chunks of the
+    // Scenes without instances, where the caller asks for it: an item is a few pixels times as many of their sample chunks as make 64 lanes -- all chunks of the
     // frame when there are at most 32 (an item is then everything the frame asks of its pixels).  The lanes of an item
     // render the same few pixels, so they have the same work ahead of them (no item whose lanes are half sky and half
     // ground, with the sky lanes out of work long before the item retires), and their primary rays are nearly the
@@ -269,7 +269,7 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     // whole items (the caller's choice: RenderTuning::split_items).
     uint32_t pix_log2 = 6u;
     const int mode = S.unroll_shift != 0u ? MODE_UNROLLED : (S.has_instances != 0u ? MODE_TWO_LEVEL : MODE_FLAT);
-    if (pipelined && tuning.split_items != 0u && mode == MODE_FLAT) {
+    if (tuning.split_items != 0u && mode == MODE_FLAT) {
 #ifdef RRT_PIPE_PIX_LOG2
         pix_log2 = RRT_PIPE_PIX_LOG2;
 #else
@@ -284,8 +284,8 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
                                ((n_chunks + (64u >> pix_log2) - 1u) >> (6u - pix_log2));
         if ((uint64_t)(n_chunks - 1u) * chunk_spp >= spp || items > 0x7FFFFFFFull) pix_log2 = 6u;
     }
-    const uint32_t tw_log2 = pipelined ? (pix_log2 == 6u ? (uint32_t)RRT_TILE_W_LOG2 : pix_log2 / 2u) : (uint32_t)RRT_TILE_W_LOG2;
-    const uint32_t tw = 1u << tw_log2, th = (pipelined ? (1u << pix_log2) : 64u) / tw, sub = pipelined ? (64u >> pix_log2) : 1u;
+    const uint32_t tw_log2 = pix_log2 == 6u ? (uint32_t)RRT_TILE_W_LOG2 : pix_log2 / 2u;
+    const uint32_t tw = 1u << tw_log2, th = (1u << pix_log2) / tw, sub = 64u >> pix_log2;
     RenderGeom G;
     G.width = width; G.height = height; G.spp = spp; G.spp_offset = spp_offset;
     G.tiles_x = (width + tw - 1u) / tw;
@@ -311,11 +311,17 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     const unsigned variant = (scaled ? 16u : 0u) | ((unsigned)mode << 2) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
     if (mode == MODE_UNROLLED) {
         e = launch_render_unrolled(count_visits, pipelined, scaled, S, G, out, d_counters, d_heads, cu_count, stream);
-    } else if (pix_log2 != 6u) {  // (scenes without instances, pipelined form: launch_render chose a split)
-        if (scaled) e = count_visits ? launch_render_variant<MODE_FLAT, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream)
-                                     : launch_render_variant<MODE_FLAT, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream);
-        else e = count_visits ? launch_render_variant<MODE_FLAT, true, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream)
-                              : launch_render_variant<MODE_FLAT, false, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream);
+    } else if (pix_log2 != 6u) {  // (scenes without instances: the items are split)
+        switch ((scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {
+            case 7u: e = launch_render_variant<MODE_FLAT, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+            case 6u: e = launch_render_variant<MODE_FLAT, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+            case 5u: e = launch_render_variant<MODE_FLAT, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+            case 4u: e = launch_render_variant<MODE_FLAT, false, false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+            case 3u: e = launch_render_variant<MODE_FLAT, true, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+            case 2u: e = launch_render_variant<MODE_FLAT, true, false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+            case 1u: e = launch_render_variant<MODE_FLAT, false, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+            default: e = launch_render_variant<MODE_FLAT, false, false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        }
     } else
     switch (variant) {
         case 19u: e = launch_render_variant<MODE_FLAT, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;

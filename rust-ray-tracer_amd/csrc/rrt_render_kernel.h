@@ -174,11 +174,27 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
         for (;;) {
             const uint32_t work = draw();
             if (work == NO_WORK) break;  // every queue is empty: this wave is done
-            const uint32_t tile = work / G.n_chunks, chunk = work % G.n_chunks;
+            uint32_t tile, chunk, x, y;
             uint32_t tx, ty;
-            tile_coords(G, tile, tx, ty);
-            const uint32_t x = tx * TILE_W + (lane & (TILE_W - 1u)), y = ty * TILE_H + (lane >> RRT_TILE_W_LOG2);
-            const bool inside = x < width && y < height;
+            bool inside;
+            if constexpr (SPLIT) {
+                // a few pixels x as many consecutive chunks of each as make 64 lanes (see the pipelined form below):
+                // the lane's pixel is the low part of its number, its chunk the item's first chunk + the high part
+                const uint32_t pix = lane & ((1u << G.pix_log2) - 1u);
+                tile = work / G.n_groups;
+                chunk = ((work % G.n_groups) << (6u - G.pix_log2)) + (lane >> G.pix_log2);
+                tile_coords(G, tile, tx, ty);
+                x = (tx << G.tw_log2) + (pix & ((1u << G.tw_log2) - 1u));
+                y = (ty << (G.pix_log2 - G.tw_log2)) + (pix >> G.tw_log2);
+                inside = x < width && y < height && chunk < G.n_chunks;
+            } else {
+                tile = work / G.n_chunks;
+                chunk = work % G.n_chunks;
+                tile_coords(G, tile, tx, ty);
+                x = tx * TILE_W + (lane & (TILE_W - 1u));
+                y = ty * TILE_H + (lane >> RRT_TILE_W_LOG2);
+                inside = x < width && y < height;
+            }
             // samples [first, first + spp) of this chunk, as absolute sample indices
             const uint32_t first = chunk * G.chunk_spp;
             const uint32_t spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;

@@ -13,6 +13,8 @@ path weight, and from the throughput form of the estimator.  Stated tolerances:
 """
 import os
 
+import itertools
+
 import numpy as np
 import pytest
 
@@ -198,23 +200,23 @@ def test_image_does_not_depend_on_the_form_of_the_box_test(rrt, monkeypatch, nam
 
 @pytest.mark.parametrize("name", ["suzanne", "synthetic", "mixed"])
 def test_image_does_not_depend_on_how_items_are_cut(rrt, monkeypatch, name):
-    """Pipelined form on scenes without instances: a work item is either 64 pixels x one sample chunk or a few pixels x
+    """Scenes without instances: a work item is either 64 pixels x one sample chunk or a few pixels x
     up to 32 consecutive chunks of each (RRT_SPLIT_ITEMS).  Every (chunk, pixel) sum is formed by one lane in sample
     order either way and the chunks are added in the same order, so the images are identical bit for bit: with 2 .. 40
     chunks (items of 32 .. 2 pixels; a last item with fewer chunks than lanes groups, a last chunk with fewer samples),
     on frames whose edges cut tiles of every shape, and with a sample offset."""
     r = rrt.Renderer(seed=21)
     r.upload(helpers.SCENES[name](rrt))
-    monkeypatch.setenv("RRT_OVERLAP_ITEMS", "1")
-    for width, height, spp, chunks, offset in ((97, 55, 12, 2, 0), (97, 55, 12, 3, 5), (64, 33, 11, 4, 0), (61, 47, 13, 5, 0),
+    for overlap, (width, height, spp, chunks, offset) in itertools.product(("0", "1"), ((97, 55, 12, 2, 0), (97, 55, 12, 3, 5), (64, 33, 11, 4, 0), (61, 47, 13, 5, 0),
                                                 (50, 31, 27, 9, 0), (41, 23, 35, 17, 3), (33, 18, 70, 35, 0), (30, 17, 40, 40, 0),
-                                                (9, 7, 64, 32, 0), (1, 1, 50, 12, 0)):
+                                                (9, 7, 64, 32, 0), (1, 1, 50, 12, 0))):
+        monkeypatch.setenv("RRT_OVERLAP_ITEMS", overlap)  # both forms of the kernel's loop over items
         monkeypatch.setenv("RRT_CHUNKS", str(chunks))
         monkeypatch.setenv("RRT_SPLIT_ITEMS", "0")
         whole, s0 = r.render(width, height, spp, spp_offset=offset)
         monkeypatch.setenv("RRT_SPLIT_ITEMS", "1")
         cut, s1 = r.render(width, height, spp, spp_offset=offset)
-        assert s0.rays == s1.rays and np.array_equal(whole, cut), (name, width, height, spp, chunks)
+        assert s0.rays == s1.rays and np.array_equal(whole, cut), (name, overlap, width, height, spp, chunks)
     r.close()
 
 
