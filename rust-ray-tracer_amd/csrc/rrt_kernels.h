@@ -43,7 +43,7 @@ struct RenderTuning {
     // same bit for bit either way (both box tests are conservative; the primitive tests decide).  Measured on MI355X:
     // 3 % faster on the 1M-triangle scene, 6-7 % on the 968-triangle and the unrolled instanced one.
     uint32_t scaled_slab = 1u;
-    // Render kernel, pipelined form: 1: a work item is a few pixels times as many of their sample chunks as make 64 lanes
+    // Render kernel, scenes without instances: 1: a work item is a few pixels times as many of their sample chunks as make 64 lanes
     // (all of the frame's chunks when there are at most 32); 0: 64 pixels times one chunk.  Same image either way.
     uint32_t split_items = 0u;
 };

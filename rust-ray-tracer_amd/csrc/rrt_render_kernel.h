@@ -32,7 +32,7 @@ static constexpr int WAVE = 64;
 #define RRT_TILE_W_LOG2 3  // a work item's 64 pixels form a tile of 2^RRT_TILE_W_LOG2 pixels' width (8x8 by default)
 #endif
 static constexpr uint32_t TILE_W = 1u << RRT_TILE_W_LOG2, TILE_H = 64u / TILE_W;
-// Pipelined form: the 64 lanes of a work item are 2^G.pix_log2 pixels (a tile of 2^G.tw_log2 pixels' width) times
+// Split items (SPLIT instantiations): the 64 lanes of a work item are 2^G.pix_log2 pixels (a tile of 2^G.tw_log2 pixels' width) times
 // 64 / pixels consecutive sample chunks of each pixel; the launcher picks the split (launch_render).  RRT_PIPE_PIX_LOG2
 // (build knob, 1 .. 6) fixes it instead.
 static constexpr int RENDER_BLOCK = 256;  // 4 independent wavefronts per workgroup
@@ -105,7 +105,7 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #endif
 // SCALED: the node steps use the scaled form of the slab arithmetic (rrt_device.h: trav_set_ray_scaled), which the host
 // selects when the scene is walked on one grid and its camera's ray directions are of ordinary magnitude.
-// SPLIT (pipelined form, scenes without instances): an item's 64 lanes are G.pix_log2 pixels times several of their
+// SPLIT (scenes without instances): an item's 64 lanes are 2^G.pix_log2 pixels times several of their
 // sample chunks instead of 64 pixels times one (launch_render picks the split); a template parameter because the
 // general index arithmetic costs the other scenes 1-3 % when it is merely switched off at run time.
 template <int MODE, bool COUNT, bool PIPELINED, bool SCALED, bool SPLIT = false>
