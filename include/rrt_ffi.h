@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define RRT_ABI_VERSION 2u  /* 2: rrt_scene_info grew by scaled_slab, reserved */
+#define RRT_ABI_VERSION 3u  /* 3: rrt_tuning + rrt_debug_{get,set}_tuning, RRT_CFG_GROUP_FORCE_RCCL; 2: rrt_scene_info grew */
 
 typedef enum rrt_status {
     RRT_OK = 0,
@@ -71,6 +71,10 @@ typedef struct rrt_config {
                                  * src/geometry/transform.rs:9-12,44-49) is written out as a world-space copy of its mesh's
                                  * tree inside the one top-level BVH; the ray changes space at the triangle test only,
                                  * on the mesh's shared object-space records.  Same hits, faster walk, more node memory. */
+#define RRT_CFG_GROUP_FORCE_RCCL 8u /* rrt_group_create only: sum the members' buffers with RCCL whenever the listed devices
+                                 * are distinct -- also in a group of ONE member, whose reduce is otherwise skipped.  Lets a
+                                 * one-GPU machine run every RCCL call of the multi-GPU path (communicator set-up, grouped
+                                 * in-place ncclReduce to member 0, stream ordering); the image is the member's own.        */
 
 /* ---- scene description: the reference's scene/material types as POD ---- */
 
@@ -199,7 +203,8 @@ typedef struct rrt_stats {
     uint64_t node_slots_lane_done;
     uint64_t node_slots_lane_at_leaf;
     float kernel_ms;      /* HIP-event time of the render kernel on its stream                              */
-    float reserved;
+    uint32_t chunks;      /* sample chunks the render was cut into (0 for a ray batch); a pixel's sum is the sum,
+                             in chunk order, of its chunks' sums                                            */
 } rrt_stats;
 
 typedef struct rrt_scene_info {
@@ -217,11 +222,38 @@ typedef struct rrt_scene_info {
     uint32_t reserved;
 } rrt_scene_info;
 
+/* ---- scheduling knobs (tests and experiments) ----  no counterpart in the reference.  How the render and ray-batch
+ * kernels cut a frame into work items and order a wavefront's passes.  None of the knobs changes which paths a pixel
+ * follows; `chunks` changes the order in which a pixel's partial sums are added (float rounding), every other knob
+ * leaves images identical bit for bit.  RRT_TUNE_AUTO in a field = the library's own rule for the scene and frame.
+ * rrt_create reads the environment ONCE (RRT_CHUNKS, RRT_SPLIT_ITEMS, RRT_NODE_SHARE, RRT_LEAVE_WALK, RRT_LEAVE_READY,
+ * RRT_OVERLAP_ITEMS, RRT_BAND_TILES, RRT_SCALED_SLAB, RRT_REFILL_MIN, RRT_BLOCKS_PER_CU, RRT_INTERSECT_STATIC) into the
+ * context's rrt_tuning; the render and intersect entry points never look at the environment.                      */
+#define RRT_TUNE_AUTO 0xFFFFFFFFu
+typedef struct rrt_tuning {
+    uint32_t chunks;           /* sample chunks a frame is cut into (1 .. spp); each chunk has a partial image        */
+    uint32_t split_items;      /* 1: work item = a few pixels x many of their chunks; 0: 64 pixels x one chunk          */
+    uint32_t node_share_64ths; /* 0..64: share of the walking lanes that must descend for a node pass to run            */
+    uint32_t leave_walk;       /* 0..63: a walk phase ends with at most this many lanes still walking ...               */
+    uint32_t leave_ready;      /* 1..64: ... once at least this many wait to shade                                      */
+    uint32_t overlap_items;    /* 1: two work items in flight per wavefront; 0: one                                     */
+    uint32_t band_tiles;       /* tiles are numbered in vertical bands this many 8-pixel tiles wide; 0: row-major       */
+    uint32_t scaled_slab;      /* 0: convert form of the box arithmetic even where the scaled form is valid             */
+    uint32_t refill_min;       /* 1..64: idle lanes that make the ray-batch kernel draw new rays                        */
+    uint32_t blocks_per_cu;    /* resident workgroups per CU of the persistent kernels (at most what the kernel allows) */
+    uint32_t intersect_static; /* 1: rrt_intersect runs the plain one-lane-per-ray kernel                               */
+    uint32_t reserved[5];      /* RRT_TUNE_AUTO                                                                         */
+} rrt_tuning;
+
 /* ---- lifetime ----  replaces: process start-up in reference src/main.rs:26-56 */
 uint32_t rrt_abi_version(void);
 rrt_status rrt_create(const rrt_config* cfg, rrt_ctx** out);
 void rrt_destroy(rrt_ctx* ctx);
 const char* rrt_last_error(const rrt_ctx* ctx);
+/* The context's scheduling knobs (see rrt_tuning).  set: takes effect from the next render / intersect call; fields
+ * out of range are clamped.  Not for use while a call on the context is in flight.                                */
+rrt_status rrt_debug_get_tuning(const rrt_ctx* ctx, rrt_tuning* out);
+rrt_status rrt_debug_set_tuning(rrt_ctx* ctx, const rrt_tuning* tuning);
 
 /* ---- scene upload ----  replaces: `BVHNode::new(objects, 0., 1.)` (reference src/gltf.rs:343,
  * src/geometry/mod.rs:161-199): the library builds a flat structure-of-arrays BVH on the host
@@ -253,10 +285,14 @@ rrt_status rrt_render_device(rrt_ctx* ctx, uint32_t width, uint32_t height, uint
  * allocation).  It launches the same kernels as rrt_render_device and gives bit-identical results, but its
  * counters, work-queue heads and per-chunk partial images live in a static workspace in device memory
  * (256 bytes + RRT_NOALLOC_PARTIAL_MAX_BYTES, held by every GPU the library runs on until the process ends) instead of
- * buffers the context grows on demand; the call allocates and frees nothing.  A frame whose partial images
- * (chunks x width x height x 12 bytes; a frame is cut into up to 32 sample chunks) exceed
- * RRT_NOALLOC_PARTIAL_MAX_BYTES is refused with RRT_ERR_INVALID.  All contexts on one GPU share that GPU's workspace:
- * calls that overlap on one GPU race (also with rrt_render_stats of an earlier such call still unread).           */
+ * buffers the context grows on demand; the call allocates and frees nothing (no device memory; on the success path no
+ * host memory either).  A frame whose partial images (chunks x width x height x 12 bytes; a frame is cut into up to 32
+ * sample chunks) exceed RRT_NOALLOC_PARTIAL_MAX_BYTES is cut into fewer, longer chunks until they fit -- the image then
+ * equals rrt_render_device's with the same chunk count (rrt_stats.chunks reports it; another count adds the same samples
+ * in another order) -- and a frame that needs chunks but of which not even two partial images fit (more than
+ * RRT_NOALLOC_PARTIAL_MAX_BYTES / 24 = 2,796,202 pixels) is refused with RRT_ERR_INVALID.  All contexts on one GPU share
+ * that GPU's workspace: calls that overlap on one GPU race (also with rrt_render_stats of an earlier such call still
+ * unread).                                                                                                         */
 #define RRT_NOALLOC_PARTIAL_MAX_BYTES (64u << 20)
 rrt_status rrt_render_device_noalloc(rrt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
                                      float* d_accum, void* stream);

@@ -33,6 +33,8 @@ RECT_FLIP_FACE = 1
 CFG_COUNT_VISITS = 1
 CFG_DEVICE_BUILD = 2
 CFG_NO_UNROLL = 4
+CFG_GROUP_FORCE_RCCL = 8
+TUNE_AUTO = 0xFFFFFFFF
 GLTF_COMPAT, GLTF_EXTENDED = 0, 1
 
 
@@ -120,7 +122,15 @@ class Stats(C.Structure):
                 ("node_wave_steps", C.c_uint64), ("prim_wave_steps", C.c_uint64), ("shade_wave_passes", C.c_uint64),
                 ("refill_wave_passes", C.c_uint64), ("node_slots_lane_done", C.c_uint64),
                 ("node_slots_lane_at_leaf", C.c_uint64),
-                ("kernel_ms", C.c_float), ("reserved", C.c_float)]
+                ("kernel_ms", C.c_float), ("chunks", C.c_uint32)]
+
+
+class Tuning(C.Structure):
+    """``rrt_tuning``: the scheduling knobs of a context (``TUNE_AUTO`` = the library's rule)."""
+    _fields_ = [("chunks", C.c_uint32), ("split_items", C.c_uint32), ("node_share_64ths", C.c_uint32),
+                ("leave_walk", C.c_uint32), ("leave_ready", C.c_uint32), ("overlap_items", C.c_uint32),
+                ("band_tiles", C.c_uint32), ("scaled_slab", C.c_uint32), ("refill_min", C.c_uint32),
+                ("blocks_per_cu", C.c_uint32), ("intersect_static", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class SceneInfo(C.Structure):
@@ -142,7 +152,8 @@ assert TRI_DTYPE.itemsize == C.sizeof(TrianglePOD)
 
 # every symbol include/rrt_ffi.h declares
 ABI_SYMBOLS = [
-    "rrt_abi_version", "rrt_create", "rrt_destroy", "rrt_last_error", "rrt_scene_upload", "rrt_scene_get_info",
+    "rrt_abi_version", "rrt_create", "rrt_destroy", "rrt_last_error", "rrt_debug_get_tuning", "rrt_debug_set_tuning",
+    "rrt_scene_upload", "rrt_scene_get_info",
     "rrt_scene_check",
     "rrt_intersect", "rrt_intersect_device", "rrt_render", "rrt_render_device", "rrt_render_stats", "rrt_tonemap",
     "rrt_tonemap_device", "rrt_selftest_arith", "rrt_gltf_load", "rrt_scene_free", "rrt_png_write",
@@ -170,6 +181,8 @@ def load_library() -> C.CDLL:
     lib.rrt_destroy.restype = None
     lib.rrt_last_error.argtypes = [vp]
     lib.rrt_last_error.restype = C.c_char_p
+    lib.rrt_debug_get_tuning.argtypes = [vp, C.POINTER(Tuning)]
+    lib.rrt_debug_set_tuning.argtypes = [vp, C.POINTER(Tuning)]
     lib.rrt_scene_upload.argtypes = [vp, C.POINTER(SceneDescPOD)]
     lib.rrt_scene_get_info.argtypes = [vp, C.POINTER(SceneInfo)]
     lib.rrt_scene_check.argtypes = [C.POINTER(SceneDescPOD), C.POINTER(SceneInfo)]
@@ -505,6 +518,23 @@ class Renderer:
         _check(self.lib.rrt_scene_upload(self.ctx, C.byref(d)), self.ctx)
         return self.info()
 
+    def tuning(self) -> Tuning:
+        t = Tuning()
+        _check(self.lib.rrt_debug_get_tuning(self.ctx, C.byref(t)), self.ctx)
+        return t
+
+    def set_tuning(self, **knobs) -> Tuning:
+        """Sets the named scheduling knobs (``rrt_debug_set_tuning``; ``None`` = back to the library's rule) and leaves
+        the others as they are: ``r.set_tuning(chunks=12, split_items=0)``.  Returns the knobs now in force."""
+        t = self.tuning()
+        names = {f[0] for f in Tuning._fields_} - {"reserved"}
+        for k, v in knobs.items():
+            if k not in names:
+                raise KeyError(k)
+            setattr(t, k, TUNE_AUTO if v is None else int(v))
+        _check(self.lib.rrt_debug_set_tuning(self.ctx, C.byref(t)), self.ctx)
+        return self.tuning()
+
     def info(self) -> SceneInfo:
         info = SceneInfo()
         _check(self.lib.rrt_scene_get_info(self.ctx, C.byref(info)), self.ctx)
@@ -560,11 +590,12 @@ class RendererGroup:
     accumulation buffers are summed on member 0.  Stands for the reference's rayon pool (``src/main.rs:42-49,86``)."""
 
     def __init__(self, devices: Sequence[int], seed: int = 1, max_depth: int = 4, t_min: float = 1e-4,
-                 count_visits: bool = False, device_build: bool = False, unroll_instances: bool = True):
+                 count_visits: bool = False, device_build: bool = False, unroll_instances: bool = True,
+                 force_rccl: bool = False):
         self.lib = load_library()
         cfg = Config(0, seed, max_depth, t_min,
                      (CFG_COUNT_VISITS if count_visits else 0) | (CFG_DEVICE_BUILD if device_build else 0) |
-                     (0 if unroll_instances else CFG_NO_UNROLL))
+                     (0 if unroll_instances else CFG_NO_UNROLL) | (CFG_GROUP_FORCE_RCCL if force_rccl else 0))
         devs = (C.c_int32 * len(devices))(*devices)
         self.grp = C.c_void_p()
         _check(self.lib.rrt_group_create(C.byref(cfg), devs, len(devices), C.byref(self.grp)), None)

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -40,11 +41,61 @@ static __device__ __align__(256) unsigned char scratch[NOALLOC_COUNTER_BYTES + N
 
 namespace {
 constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;                      // contexts may be created from several host threads at once
 unsigned char* g_scratch_ptr[MAX_DEVICES] = {};  // per device ordinal: address of that device's `scratch`
+
+// Address of the CURRENT device's copy of `scratch` (the caller has made `device` current); asked of the runtime once
+// per device.
+hipError_t static_workspace(int device, unsigned char** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        unsigned char* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!ptr) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
+// The scheduling knobs of a new context: the library's own rules (RRT_TUNE_AUTO) unless the environment names a value.
+// Read once per rrt_create; the render and intersect entry points only look at the context's copy.
+uint32_t env_u32(const char* name, uint32_t lo, uint32_t hi) {
+    const char* e = std::getenv(name);
+    if (!e || !*e) return RRT_TUNE_AUTO;
+    const long long v = std::atoll(e);
+    return (uint32_t)std::max<long long>(lo, std::min<long long>(hi, v));
+}
+rrt_tuning tuning_from_env() {
+    rrt_tuning t;
+    t.chunks = env_u32("RRT_CHUNKS", 1u, 0x7FFFFFFFu);
+    t.split_items = env_u32("RRT_SPLIT_ITEMS", 0u, 1u);
+    t.node_share_64ths = env_u32("RRT_NODE_SHARE", 0u, 64u);
+    t.leave_walk = env_u32("RRT_LEAVE_WALK", 0u, 63u);
+    t.leave_ready = env_u32("RRT_LEAVE_READY", 1u, 64u);
+    t.overlap_items = env_u32("RRT_OVERLAP_ITEMS", 0u, 1u);
+    t.band_tiles = env_u32("RRT_BAND_TILES", 0u, 0x7FFFFFFFu);
+    t.scaled_slab = env_u32("RRT_SCALED_SLAB", 0u, 1u);
+    t.refill_min = env_u32("RRT_REFILL_MIN", 1u, 64u);
+    t.blocks_per_cu = env_u32("RRT_BLOCKS_PER_CU", 1u, 64u);
+    t.intersect_static = env_u32("RRT_INTERSECT_STATIC", 0u, 1u);
+    for (uint32_t& r : t.reserved) r = RRT_TUNE_AUTO;
+    return t;
+}
+rrt_tuning clamp_tuning(rrt_tuning t) {
+    auto cl = [](uint32_t& v, uint32_t lo, uint32_t hi) { if (v != RRT_TUNE_AUTO) v = std::max(lo, std::min(hi, v)); };
+    cl(t.chunks, 1u, 0x7FFFFFFFu); cl(t.split_items, 0u, 1u); cl(t.node_share_64ths, 0u, 64u); cl(t.leave_walk, 0u, 63u);
+    cl(t.leave_ready, 1u, 64u); cl(t.overlap_items, 0u, 1u); cl(t.band_tiles, 0u, 0x7FFFFFFFu); cl(t.scaled_slab, 0u, 1u);
+    cl(t.refill_min, 1u, 64u); cl(t.blocks_per_cu, 1u, 64u); cl(t.intersect_static, 0u, 1u);
+    for (uint32_t& r : t.reserved) r = RRT_TUNE_AUTO;
+    return t;
+}
 }  // namespace
 
 struct rrt_ctx {
     rrt_config cfg{};
+    rrt_tuning tune{};  // scheduling knobs: the environment as rrt_create found it, or rrt_debug_set_tuning
     std::string err;
     bool has_scene = false;
     SceneDev sdev{};
@@ -66,6 +117,7 @@ struct rrt_ctx {
     bool render_pending = false;
     uint64_t pending_samples = 0;
     uint64_t pending_rays = 0;  // ray count of a pending ray batch (its kernel does not count rays itself)
+    uint32_t pending_chunks = 0;  // sample chunks of the pending render
 };
 
 namespace {
@@ -219,18 +271,26 @@ rrt_status rrt_create(const rrt_config* cfg, rrt_ctx** out) {
     }
     // address of THIS device's copy of the static workspace (the device is current); looked up once per device
     if (cfg->device < MAX_DEVICES) {
-        if (!g_scratch_ptr[cfg->device]) {
-            unsigned char* ptr = nullptr;
-            if ((e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch))) != hipSuccess || !ptr) {
-                rrt_status st = hip_fail(nullptr, e, "rrt_create: hipGetSymbolAddress(scratch)");
-                rrt_destroy(c);
-                return st;
-            }
-            g_scratch_ptr[cfg->device] = ptr;
+        if ((e = static_workspace(cfg->device, &c->d_static)) != hipSuccess) {
+            rrt_status st = hip_fail(nullptr, e, "rrt_create: hipGetSymbolAddress(scratch)");
+            rrt_destroy(c);
+            return st;
         }
-        c->d_static = g_scratch_ptr[cfg->device];
     }
+    c->tune = tuning_from_env();
     *out = c;
+    return RRT_OK;
+}
+
+rrt_status rrt_debug_get_tuning(const rrt_ctx* c, rrt_tuning* out) {
+    if (!c || !out) return set_err(nullptr, RRT_ERR_INVALID, "rrt_debug_get_tuning: NULL argument");
+    *out = c->tune;
+    return RRT_OK;
+}
+
+rrt_status rrt_debug_set_tuning(rrt_ctx* c, const rrt_tuning* tuning) {
+    if (!c || !tuning) return set_err(c, RRT_ERR_INVALID, "rrt_debug_set_tuning: NULL argument");
+    c->tune = clamp_tuning(*tuning);
     return RRT_OK;
 }
 
@@ -428,8 +488,11 @@ rrt_status rrt_intersect_device(rrt_ctx* c, const rrt_ray* d_rays, size_t n, flo
     if (n > 0xF0000000ull) return set_err(c, RRT_ERR_INVALID, "rrt_intersect_device: batch too large");
     hipStream_t s = (hipStream_t)stream;
     RenderTuning tuning;
-    if (const char* e = std::getenv("RRT_NODE_SHARE")) tuning.node_share_64ths = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("RRT_REFILL_MIN")) tuning.refill_min = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
+    const rrt_tuning& tn = c->tune;
+    if (tn.node_share_64ths != RRT_TUNE_AUTO) tuning.node_share_64ths = tn.node_share_64ths;
+    if (tn.refill_min != RRT_TUNE_AUTO) tuning.refill_min = tn.refill_min;
+    if (tn.blocks_per_cu != RRT_TUNE_AUTO) tuning.blocks_per_cu = tn.blocks_per_cu;
+    if (tn.intersect_static != RRT_TUNE_AUTO) tuning.intersect_static = tn.intersect_static;
     if (rrt_status st = order_after_pending(c, s)) return st;
     RRT_HIP(c, hipMemsetAsync(c->d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
@@ -441,6 +504,7 @@ rrt_status rrt_intersect_device(rrt_ctx* c, const rrt_ray* d_rays, size_t n, flo
     c->render_pending = true;
     c->pending_samples = 0;
     c->pending_rays = n;
+    c->pending_chunks = 0;
     c->last_counters = c->d_counters;
     return RRT_OK;
 }
@@ -465,21 +529,26 @@ rrt_status rrt_intersect(rrt_ctx* c, const rrt_ray* rays, size_t n, float t_min,
 }  // extern "C"
 
 // Shared body of rrt_render_device and rrt_render_device_noalloc.  `noalloc`: counters, work-queue heads and partial
-// images live in the device's static workspace and nothing is allocated; frames whose partial images exceed that
-// workspace are refused.
+// images live in the device's static workspace and nothing is allocated (no device memory, and on the success path no
+// host memory either: messages are only built when a call fails); a frame whose partial images would exceed that
+// workspace is cut into fewer sample chunks until they fit.
+static rrt_status render_fail(rrt_ctx* c, rrt_status st, const char* fn, const char* what) {
+    return set_err(c, st, std::string(fn) + ": " + what);
+}
+
 static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset, float* d_accum,
                               void* stream, bool noalloc, const char* fn) {
-    const std::string who = fn;
-    if (!c) return set_err(nullptr, RRT_ERR_INVALID, who + ": ctx is NULL");
-    if (!c->has_scene) return set_err(c, RRT_ERR_STATE, who + ": no scene uploaded");
-    if (!d_accum) return set_err(c, RRT_ERR_INVALID, who + ": accum is NULL");
-    if (width == 0 || height == 0 || spp == 0) return set_err(c, RRT_ERR_INVALID, who + ": width, height and spp must be > 0");
+    if (!c) return render_fail(nullptr, RRT_ERR_INVALID, fn, "ctx is NULL");
+    if (!c->has_scene) return render_fail(c, RRT_ERR_STATE, fn, "no scene uploaded");
+    if (!d_accum) return render_fail(c, RRT_ERR_INVALID, fn, "accum is NULL");
+    if (width == 0 || height == 0 || spp == 0) return render_fail(c, RRT_ERR_INVALID, fn, "width, height and spp must be > 0");
     // the kernels index the image's floats with 32 bits
-    if ((uint64_t)width * height > (0xFFFFFFFFull - 255ull) / 3ull) return set_err(c, RRT_ERR_INVALID, who + ": image too large");
-    if ((uint64_t)spp + spp_offset > 0xFFFFFFFFull) return set_err(c, RRT_ERR_INVALID, who + ": sample index overflows");
-    if (noalloc && !c->d_static) return set_err(c, RRT_ERR_STATE, who + ": no static workspace on this device");
+    if ((uint64_t)width * height > (0xFFFFFFFFull - 255ull) / 3ull) return render_fail(c, RRT_ERR_INVALID, fn, "image too large");
+    if ((uint64_t)spp + spp_offset > 0xFFFFFFFFull) return render_fail(c, RRT_ERR_INVALID, fn, "sample index overflows");
+    if (noalloc && !c->d_static) return render_fail(c, RRT_ERR_STATE, fn, "no static workspace on this device");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     hipStream_t s = (hipStream_t)stream;
+    const rrt_tuning& tn = c->tune;
     // Scenes with a real hierarchy (>= 4096 nodes): paths bounce and walks are long, so items of 8 samples, the
     // straggler rule and lanes that move on to the next item by themselves pay; on tiny scenes each of them costs.
     const bool big_scene = c->info.node_count >= 4096u;
@@ -494,45 +563,42 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     if (huge_scene && spp >= 128u && pixels >= 24000000ull) per_item = 32u;
     // Items of a few pixels x many of their chunks (launch_render) on every other scene without instances that has
     // pixels of unequal cost to even out: suzanne 1080p x 256 spp 11.1 -> 10.6 ms, x 1024 spp 32.7 -> 29.9 ms; not on
-    // scenes of a few primitives (12-primitive scene 0.94 -> 1.03 ms with it).  RRT_SPLIT_ITEMS overrides the rule.
-    bool split_items = !huge_scene && c->info.node_count >= 64u;
-    if (const char* e = std::getenv("RRT_SPLIT_ITEMS")) split_items = std::atoi(e) != 0;
+    // scenes of a few primitives (12-primitive scene 0.94 -> 1.03 ms with it).
+    bool split_items = tn.split_items != RRT_TUNE_AUTO ? tn.split_items != 0u : (!huge_scene && c->info.node_count >= 64u);
     uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? per_item : 16u);
-    if (const char* e = std::getenv("RRT_CHUNKS")) {
-        const int v = std::atoi(e);
-        if (v >= 1) n_chunks = std::min<uint32_t>((uint32_t)v, spp);
-    }
+    if (tn.chunks != RRT_TUNE_AUTO) n_chunks = std::min(tn.chunks, spp);
     while (n_chunks > 1u && (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * n_chunks > 0x7FFFFFFFull) n_chunks /= 2u;
-    // Split items hold a power of two of chunks side by side (launch_render) and pay only while every lane of an item has
-    // the same number of samples to render: the power of two nearest to the count chosen above (within a factor of two)
-    // that divides the sample count; whole tiles where there is none.  Measured on MI355X, 1M-triangle scene at 4K:
-    // 100 spp as 13 chunks in 16 slots 148.1 ms, as 8 chunks of 13 (the last of 9) 125.1 ms, whole tiles 123.1 ms; 96 spp
-    // as 12 chunks in 16 slots 147.4 ms, as 8 or 16 equal chunks 116.3 ms.  (RRT_CHUNKS is taken as it is.)
-    if (split_items && n_chunks > 1u && !std::getenv("RRT_CHUNKS")) {
+    // Split items hold a power of two of chunks side by side (launch_render): the power of two from 8 to 32 nearest (in
+    // ratio, within a factor of two) to the count chosen above; whole tiles where there is none.  Chunk lengths differ
+    // by at most one sample (RenderGeom), so every sample count splits: 100 spp are 16 chunks of 6 or 7 samples.  (A
+    // chunk count the caller fixed is taken as it is.)
+    if (split_items && n_chunks > 1u && tn.chunks == RRT_TUNE_AUTO) {
         uint32_t best = 0u;
         for (uint32_t p = 8u; p <= 32u; p *= 2u) {  // (items of 16 pixels and more are no better than whole tiles)
-            if (spp % p != 0u || p > 2u * n_chunks || n_chunks > 2u * p) continue;
+            if (p > spp || p > 2u * n_chunks || n_chunks > 2u * p) continue;
             // nearer to the chosen count in ratio; of two equally near ones the larger
             if (best == 0u || (p >= n_chunks ? (uint64_t)p * best <= (uint64_t)n_chunks * n_chunks : true)) best = p;
         }
         if (best != 0u) n_chunks = best;
         else split_items = false;
     }
-    if (n_chunks <= 1u) split_items = false;
-    // No chunk may be empty: a chunk holds ceil(spp / n_chunks) samples, so only ceil(spp / that) chunks have any
-    // (50 samples in 12 chunks are 10 chunks of 5), and the kernel writes a partial image only for chunks with samples.
-    {
-        const uint32_t chunk_spp = (spp + n_chunks - 1u) / n_chunks;
-        n_chunks = (spp + chunk_spp - 1u) / chunk_spp;
+    // The static workspace holds so many partial images and no more: fewer, longer chunks until they fit (the sum of a
+    // pixel's samples is then formed in another order than rrt_render_device forms it: same samples, last-bit
+    // differences).  One chunk needs no partial image at all.
+    if (noalloc && n_chunks > 1u) {
+        const uint64_t image_bytes = pixels * 3ull * sizeof(float);
+        const uint64_t fit = NOALLOC_PARTIAL_BYTES / image_bytes;  // partial images the workspace holds
+        if (fit < 2u)
+            return set_err(c, RRT_ERR_INVALID, std::string(fn) + ": a frame of " + std::to_string(pixels) + " pixels is cut into sample chunks, and the static workspace (" +
+                                                   std::to_string(NOALLOC_PARTIAL_BYTES) + " bytes) does not hold two partial images of " +
+                                                   std::to_string(image_bytes) + " bytes; use rrt_render_device");
+        while ((uint64_t)n_chunks > fit) n_chunks /= 2u;  // (stays >= 2, and a power of two where it was one)
     }
+    if (n_chunks <= 1u) split_items = false;
     const size_t need = n_chunks > 1u ? (size_t)n_chunks * width * height * 3u * sizeof(float) : 0u;
     float* d_partial = nullptr;
     unsigned long long* d_counters = nullptr;
     if (noalloc) {
-        if (need > NOALLOC_PARTIAL_BYTES)
-            return set_err(c, RRT_ERR_INVALID, who + ": this frame needs " + std::to_string(need) + " bytes of partial images (" +
-                                                   std::to_string(n_chunks) + " sample chunks), the static workspace holds " +
-                                                   std::to_string(NOALLOC_PARTIAL_BYTES) + "; use rrt_render_device");
         d_counters = reinterpret_cast<unsigned long long*>(c->d_static);
         d_partial = reinterpret_cast<float*>(c->d_static + NOALLOC_COUNTER_BYTES);
     } else {
@@ -548,9 +614,7 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
         d_counters = c->d_counters;
         d_partial = c->d_partial;
     }
-    // tuning overrides for experiments: RRT_CHUNKS (above), RRT_NODE_SHARE (0..64)
     RenderTuning tuning;
-    if (const char* e = std::getenv("RRT_NODE_SHARE")) tuning.node_share_64ths = (uint32_t)std::max(0, std::min(64, std::atoi(e)));
     if (!big_scene) {
         tuning.leave_walk = 0u;
         tuning.overlap_items = 0u;
@@ -567,11 +631,13 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
         // (measured on MI355X, ten million triangles: 12 -> 20 is 1-2 % faster, flat and unrolled alike)
         tuning.leave_walk = 20u;
     }
-    if (const char* e = std::getenv("RRT_LEAVE_WALK")) tuning.leave_walk = (uint32_t)std::max(0, std::min(63, std::atoi(e)));
-    if (const char* e = std::getenv("RRT_LEAVE_READY")) tuning.leave_ready = (uint32_t)std::max(1, std::min(64, std::atoi(e)));
-    if (const char* e = std::getenv("RRT_OVERLAP_ITEMS")) tuning.overlap_items = std::atoi(e) != 0 ? 1u : 0u;
-    if (const char* e = std::getenv("RRT_BAND_TILES")) tuning.band_tiles = (uint32_t)std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("RRT_SCALED_SLAB")) tuning.scaled_slab = std::atoi(e) != 0 ? 1u : 0u;
+    if (tn.node_share_64ths != RRT_TUNE_AUTO) tuning.node_share_64ths = tn.node_share_64ths;
+    if (tn.leave_walk != RRT_TUNE_AUTO) tuning.leave_walk = tn.leave_walk;
+    if (tn.leave_ready != RRT_TUNE_AUTO) tuning.leave_ready = tn.leave_ready;
+    if (tn.overlap_items != RRT_TUNE_AUTO) tuning.overlap_items = tn.overlap_items;
+    if (tn.band_tiles != RRT_TUNE_AUTO) tuning.band_tiles = tn.band_tiles;
+    if (tn.scaled_slab != RRT_TUNE_AUTO) tuning.scaled_slab = tn.scaled_slab;
+    if (tn.blocks_per_cu != RRT_TUNE_AUTO) tuning.blocks_per_cu = tn.blocks_per_cu;
     if (rrt_status st = order_after_pending(c, s)) return st;
     RRT_HIP(c, hipMemsetAsync(d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
@@ -583,6 +649,7 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     c->render_pending = true;
     c->pending_samples = (uint64_t)width * height * spp;
     c->pending_rays = 0;
+    c->pending_chunks = n_chunks;
     c->last_counters = d_counters;
     return RRT_OK;
 }
@@ -620,6 +687,7 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     stats->node_slots_lane_at_leaf = h[13];
     stats->samples = c->pending_samples;
     stats->kernel_ms = ms;
+    stats->chunks = c->pending_chunks;
     return RRT_OK;
 }
 
@@ -710,23 +778,25 @@ struct RcclApi {
     bool ok = false;
 };
 
+// librccl, opened the first time a group wants it (once per process, whichever thread comes first); nullptr when the
+// library or one of its entry points is missing.
 RcclApi* rccl_api() {
     static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.ok ? &api : nullptr;
-    tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (api.handle) break;
-    }
-    if (!api.handle) return nullptr;
-    api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(api.handle, "ncclCommInitAll"));
-    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
-    api.Reduce = reinterpret_cast<decltype(api.Reduce)>(dlsym(api.handle, "ncclReduce"));
-    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.handle, "ncclGroupStart"));
-    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.handle, "ncclGroupEnd"));
-    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
-    api.ok = api.CommInitAll && api.CommDestroy && api.Reduce && api.GroupStart && api.GroupEnd && api.GetErrorString;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+        if (!api.handle) return;
+        api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(dlsym(api.handle, "ncclCommInitAll"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+        api.Reduce = reinterpret_cast<decltype(api.Reduce)>(dlsym(api.handle, "ncclReduce"));
+        api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(api.handle, "ncclGroupStart"));
+        api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(api.handle, "ncclGroupEnd"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+        api.ok = api.CommInitAll && api.CommDestroy && api.Reduce && api.GroupStart && api.GroupEnd && api.GetErrorString;
+    });
     return api.ok ? &api : nullptr;
 }
 
@@ -794,18 +864,29 @@ rrt_status rrt_group_create(const rrt_config* cfg, const int32_t* devices, uint3
         g->d_accum.push_back(nullptr);
         if (e != hipSuccess) return fail(RRT_ERR_HIP, std::string("rrt_group_create: ") + hipGetErrorString(e));
     }
+    // The sum goes through RCCL when the listed devices are distinct and there is somebody to sum with -- or nobody,
+    // but the caller asked for the RCCL calls all the same (RRT_CFG_GROUP_FORCE_RCCL: a one-GPU machine then runs
+    // communicator set-up, the grouped reduce and its stream ordering).  Without librccl, or when the communicators
+    // cannot be set up, the members' buffers are copied to member 0 and added there.
     g->reduce_path = n_devices == 1u ? "none" : "copy+add";
-    if (n_devices > 1u && distinct && !std::getenv("RRT_GROUP_NO_RCCL")) {
+    const bool force = (cfg->flags & RRT_CFG_GROUP_FORCE_RCCL) != 0u;
+    if ((n_devices > 1u || force) && distinct && !std::getenv("RRT_GROUP_NO_RCCL")) {
         if (RcclApi* api = rccl_api()) {
-            g->comms.resize(n_devices);
+            g->comms.assign(n_devices, nullptr);
             std::vector<int> devs(devices, devices + n_devices);
             const ncclResult_t r = api->CommInitAll(g->comms.data(), (int)n_devices, devs.data());
-            if (r != ncclSuccess) {
+            if (r == ncclSuccess) {
+                g->reduce_path = "rccl";
+            } else {
                 g->comms.clear();
-                return fail(RRT_ERR_HIP, std::string("rrt_group_create: ncclCommInitAll: ") + api->GetErrorString(r));
+                g->err = std::string("ncclCommInitAll: ") + api->GetErrorString(r) + " (summing by copy and add instead)";
+                if (force) return fail(RRT_ERR_HIP, "rrt_group_create: " + g->err);
             }
-            g->reduce_path = "rccl";
+        } else if (force) {
+            return fail(RRT_ERR_HIP, "rrt_group_create: RRT_CFG_GROUP_FORCE_RCCL, but librccl could not be opened");
         }
+    } else if (force) {
+        return fail(RRT_ERR_INVALID, "rrt_group_create: RRT_CFG_GROUP_FORCE_RCCL needs distinct devices (and RRT_GROUP_NO_RCCL unset)");
     }
     *out = g.release();
     return RRT_OK;
@@ -875,7 +956,11 @@ rrt_status rrt_group_render(rrt_group* g, uint32_t width, uint32_t height, uint3
     if (!accum) return group_err(g, RRT_ERR_INVALID, "rrt_group_render: accum is NULL");
     if (width == 0 || height == 0 || spp_total == 0) return group_err(g, RRT_ERR_INVALID, "rrt_group_render: width, height and spp must be > 0");
     if ((uint64_t)width * height > (0xFFFFFFFFull - 255ull) / 3ull) return group_err(g, RRT_ERR_INVALID, "rrt_group_render: image too large");
+    // (checked here for all members, so that no member is launched when another one's slice would be refused)
+    if ((uint64_t)spp_total + spp_offset > 0xFFFFFFFFull) return group_err(g, RRT_ERR_INVALID, "rrt_group_render: sample index overflows");
     const size_t n = g->members.size();
+    for (size_t i = 0; i < n; ++i)
+        if (!g->members[i]->has_scene) return group_member_err(g, i, set_err(g->members[i], RRT_ERR_STATE, "rrt_group_render: no scene uploaded"));
     const size_t n_floats = (size_t)width * height * 3u, bytes = n_floats * sizeof(float);
     if (bytes > g->accum_bytes) {
         for (size_t i = 0; i < n; ++i) {
@@ -910,11 +995,20 @@ rrt_status rrt_group_render(rrt_group* g, uint32_t width, uint32_t height, uint3
             RRT_GHIP(g, hipMemsetAsync(g->d_accum[i], 0, bytes, g->streams[i]));
         } else {
             const rrt_status st = rrt_render_device(c, width, height, count[i], first[i], g->d_accum[i], g->streams[i]);
-            if (st != RRT_OK) return group_member_err(g, i, st);
+            if (st != RRT_OK) {
+                // the members launched so far still write their buffers: drained before the caller gets the error
+                for (size_t k = 0; k < i; ++k) {
+                    (void)hipSetDevice(g->members[k]->cfg.device);
+                    (void)hipStreamSynchronize(g->streams[k]);
+                }
+                return group_member_err(g, i, st);
+            }
         }
     }
     // the exchange step: sum of the members' buffers on member 0
-    if (n > 1 && !g->comms.empty()) {
+    if (!g->comms.empty()) {
+        // One in-place ncclReduce per member, root = member 0, issued as one group on the members' own streams: each
+        // stream runs its member's render first, then its part of the reduce, so nothing else has to order them.
         RcclApi* api = rccl_api();
         ncclResult_t r = api->GroupStart();
         for (size_t i = 0; i < n && r == ncclSuccess; ++i)
@@ -954,7 +1048,8 @@ rrt_status rrt_group_render(rrt_group* g, uint32_t width, uint32_t height, uint3
         if (rs != RRT_OK) return group_member_err(g, i, rs);
         total.rays += st.rays; total.samples += st.samples; total.node_visits += st.node_visits; total.prim_tests += st.prim_tests;
         total.node_wave_steps += st.node_wave_steps; total.prim_wave_steps += st.prim_wave_steps;
-        total.shade_wave_passes += st.shade_wave_passes;
+        total.shade_wave_passes += st.shade_wave_passes; total.refill_wave_passes += st.refill_wave_passes;
+        total.chunks = std::max(total.chunks, st.chunks);
         total.node_slots_lane_done += st.node_slots_lane_done; total.node_slots_lane_at_leaf += st.node_slots_lane_at_leaf;
         total.kernel_ms = std::max(total.kernel_ms, st.kernel_ms);  // the members render side by side
     }

@@ -336,10 +336,10 @@ typedef __attribute__((address_space(3))) int lds_int;
 //   MODE_TWO_LEVEL  instance leaves in the top-level BVH; a lane that reaches one changes its ray's space and walks the
 //                   mesh's own BVH (reference src/geometry/transform.rs:22-31,99-130 as it stands).
 //   MODE_UNROLLED   every instance's copy of its mesh's BVH is part of ONE tree whose boxes are all in world space; the
-//                   change of space happens at the triangle test only: a triangle leaf's reference carries the instance
+//                   change of space happens at the primitive test only: a leaf's reference carries the instance
 //                   (slot << S.unroll_shift | first record, slot 0 = not instanced), the lane transforms its ray with that
 //                   instance's record (S.insts[slot - 1]; S.insts[-1] is an identity record) and runs the reference's
-//                   test on the mesh's object-space triangle record.  Same primitive tests on the same operands as
+//                   test on the mesh's object-space triangle, sphere or rectangle record.  Same primitive tests on the same operands as
 //                   the two-level walk, so the same hits; no markers, no second grid, no parked rays.
 static constexpr int MODE_FLAT = 0, MODE_TWO_LEVEL = 1, MODE_UNROLLED = 2;
 
@@ -643,15 +643,15 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
     const uint32_t kind = (ref >> 28) & 7u;
     uint32_t first = ref & REF_OFFSET_MASK;
     V3 ro = o, rd = d;  // the ray in the space being walked
-    int32_t tri_inst = T.cur_inst;  // instance a triangle of this leaf belongs to
+    int32_t tri_inst = T.cur_inst;  // instance the primitives of this leaf belong to
     uint32_t first_mask = REF_OFFSET_MASK;
     if (MODE == MODE_UNROLLED) {
-        // a triangle leaf names its instance: the ray goes into that instance's space for the test, exactly as
+        // a leaf names its instance: the ray goes into that instance's space for the test, exactly as
         // Translate::hit and RotateY::hit move it (transform.rs:24,101-108); slot 0 (inst -1) reads the identity
         // record in front of the array and keeps the ray as it is
         first_mask = (1u << S.unroll_shift) - 1u;
-        tri_inst = kind == KIND_TRI ? (int32_t)(first >> S.unroll_shift) - 1 : -1;
-        first &= kind == KIND_TRI ? first_mask : REF_OFFSET_MASK;
+        tri_inst = (int32_t)(first >> S.unroll_shift) - 1;
+        first &= first_mask;
         // (the record comes from the workgroup's LDS copy of the table when the kernel keeps one: a load through the
         // vector L1 takes its address unit 16 cycles whatever the number of lanes, and that unit is as busy as the SIMDs)
         float4 x0, x1;
@@ -712,10 +712,10 @@ __device__ __forceinline__ void trav_leaf(const SceneDev& S, V3& o, V3& d, float
             return;
         }
     } else if (kind == KIND_SPHERE) {
-        test_sphere(S, first, ro, rd, tmin, T.cur_inst, T.best);
+        test_sphere(S, first, ro, rd, tmin, tri_inst, T.best);
         if (COUNT) cnt.prims++;
     } else if (kind == KIND_RECT) {
-        test_rect(S, first, ro, rd, tmin, T.cur_inst, T.best);
+        test_rect(S, first, ro, rd, tmin, tri_inst, T.best);
         if (COUNT) cnt.prims++;
     } else if (INST && kind == KIND_INST) {
         const InstRec in = S.insts[first];

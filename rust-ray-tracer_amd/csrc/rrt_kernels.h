@@ -46,11 +46,16 @@ struct RenderTuning {
     // Render kernel, scenes without instances: 1: a work item is a few pixels times as many of their sample chunks as make 64 lanes
     // (all of the frame's chunks when there are at most 32); 0: 64 pixels times one chunk.  Same image either way.
     uint32_t split_items = 0u;
+    // Persistent kernels: fewer resident workgroups per CU than the kernel allows (0: all of them; occupancy experiments).
+    uint32_t blocks_per_cu = 0u;
+    // Ray batches: 1 runs the plain one-lane-per-ray kernel instead of the streaming one (experiments).
+    uint32_t intersect_static = 0u;
 };
 
 // d_counters: 7 x u64 in device memory {rays, node visits, primitive tests, wave-level node passes, primitive
 //             passes, shading passes, refill passes}; the kernels ADD to them.
 // d_heads:    8 x u32 work-queue heads, zero before the launch.
+// n_chunks (1 .. spp) sample chunks whose lengths differ by at most one (RenderGeom).
 // n_chunks > 1: the kernel writes n_chunks partial images (each width*height*3 floats) to d_partial and a second
 // kernel sums them into d_accum in chunk order; n_chunks == 1: the kernel writes d_accum directly.
 hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,

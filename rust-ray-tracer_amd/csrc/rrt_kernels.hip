@@ -267,6 +267,7 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     // same ray.  Measured on MI355X against 64 pixels x one chunk: 1M-triangle scene at 1024 spp 1177 -> 1124 ms
     // (154.9 -> 151.9 ms at 128 spp), MetalRoughSpheres 358 -> 331 ms; ten-million-triangle scenes lose 1-3 % and keep
     // whole items (the caller's choice: RenderTuning::split_items).
+    if (n_chunks == 0u || n_chunks > spp) return hipErrorInvalidValue;  // every chunk holds at least one sample
     uint32_t pix_log2 = 6u;
     const int mode = S.unroll_shift != 0u ? MODE_UNROLLED : (S.has_instances != 0u ? MODE_TWO_LEVEL : MODE_FLAT);
     if (tuning.split_items != 0u && mode == MODE_FLAT) {
@@ -277,12 +278,11 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
         while (sub_log2 < 5u && (1u << sub_log2) < n_chunks) ++sub_log2;  // chunks per item: the power of two that holds them all, at most 32
         pix_log2 = 6u - sub_log2;
 #endif
-        // the split form takes every chunk but the last as full and the last as not empty (the library's callers see to
-        // that), and its items are numbered with 31 bits like the others: whole tiles otherwise
-        const uint32_t chunk_spp = (spp + n_chunks - 1u) / n_chunks, w_log2 = pix_log2 / 2u, h_log2 = pix_log2 - w_log2;
+        // split items are numbered with 31 bits like the others: whole tiles otherwise
+        const uint32_t w_log2 = pix_log2 / 2u, h_log2 = pix_log2 - w_log2;
         const uint64_t items = (uint64_t)((width + (1u << w_log2) - 1u) >> w_log2) * ((height + (1u << h_log2) - 1u) >> h_log2) *
                                ((n_chunks + (64u >> pix_log2) - 1u) >> (6u - pix_log2));
-        if ((uint64_t)(n_chunks - 1u) * chunk_spp >= spp || items > 0x7FFFFFFFull) pix_log2 = 6u;
+        if (items > 0x7FFFFFFFull) pix_log2 = 6u;
     }
     const uint32_t tw_log2 = pix_log2 == 6u ? (uint32_t)RRT_TILE_W_LOG2 : pix_log2 / 2u;
     const uint32_t tw = 1u << tw_log2, th = (1u << pix_log2) / tw, sub = 64u >> pix_log2;
@@ -296,7 +296,8 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     G.band_items = G.band_tiles * ((height + th - 1u) / th);
     G.full_bands = G.tiles_x / G.band_tiles;
     G.n_chunks = n_chunks;
-    G.chunk_spp = (spp + n_chunks - 1u) / n_chunks;
+    G.chunk_q = spp / n_chunks;
+    G.chunk_r = spp % n_chunks;
     G.n_groups = (n_chunks + sub - 1u) / sub;
     G.pix_log2 = pix_log2;
     G.tw_log2 = tw_log2;
@@ -310,32 +311,32 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     const bool scaled = S.sigma != 0.0f && tuning.scaled_slab != 0u && mode != MODE_TWO_LEVEL;
     const unsigned variant = (scaled ? 16u : 0u) | ((unsigned)mode << 2) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
     if (mode == MODE_UNROLLED) {
-        e = launch_render_unrolled(count_visits, pipelined, scaled, S, G, out, d_counters, d_heads, cu_count, stream);
+        e = launch_render_unrolled(count_visits, pipelined, scaled, S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream);
     } else if (pix_log2 != 6u) {  // (scenes without instances: the items are split)
         switch ((scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {
-            case 7u: e = launch_render_variant<MODE_FLAT, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-            case 6u: e = launch_render_variant<MODE_FLAT, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-            case 5u: e = launch_render_variant<MODE_FLAT, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-            case 4u: e = launch_render_variant<MODE_FLAT, false, false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-            case 3u: e = launch_render_variant<MODE_FLAT, true, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-            case 2u: e = launch_render_variant<MODE_FLAT, true, false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-            case 1u: e = launch_render_variant<MODE_FLAT, false, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-            default: e = launch_render_variant<MODE_FLAT, false, false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+            case 7u: e = launch_render_variant<MODE_FLAT, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 6u: e = launch_render_variant<MODE_FLAT, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 5u: e = launch_render_variant<MODE_FLAT, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 4u: e = launch_render_variant<MODE_FLAT, false, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 3u: e = launch_render_variant<MODE_FLAT, true, true, false, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 2u: e = launch_render_variant<MODE_FLAT, true, false, false, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 1u: e = launch_render_variant<MODE_FLAT, false, true, false, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            default: e = launch_render_variant<MODE_FLAT, false, false, false, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
         }
     } else
     switch (variant) {
-        case 19u: e = launch_render_variant<MODE_FLAT, true, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 18u: e = launch_render_variant<MODE_FLAT, true, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 17u: e = launch_render_variant<MODE_FLAT, false, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 16u: e = launch_render_variant<MODE_FLAT, false, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 7u: e = launch_render_variant<MODE_TWO_LEVEL, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 6u: e = launch_render_variant<MODE_TWO_LEVEL, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 5u: e = launch_render_variant<MODE_TWO_LEVEL, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 4u: e = launch_render_variant<MODE_TWO_LEVEL, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 3u: e = launch_render_variant<MODE_FLAT, true, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 2u: e = launch_render_variant<MODE_FLAT, true, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        case 1u: e = launch_render_variant<MODE_FLAT, false, true>(S, G, out, d_counters, d_heads, cu_count, stream); break;
-        default: e = launch_render_variant<MODE_FLAT, false, false>(S, G, out, d_counters, d_heads, cu_count, stream); break;
+        case 19u: e = launch_render_variant<MODE_FLAT, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 18u: e = launch_render_variant<MODE_FLAT, true, false, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 17u: e = launch_render_variant<MODE_FLAT, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 16u: e = launch_render_variant<MODE_FLAT, false, false, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 7u: e = launch_render_variant<MODE_TWO_LEVEL, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 6u: e = launch_render_variant<MODE_TWO_LEVEL, true, false>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 5u: e = launch_render_variant<MODE_TWO_LEVEL, false, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 4u: e = launch_render_variant<MODE_TWO_LEVEL, false, false>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 3u: e = launch_render_variant<MODE_FLAT, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 2u: e = launch_render_variant<MODE_FLAT, true, false>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        case 1u: e = launch_render_variant<MODE_FLAT, false, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        default: e = launch_render_variant<MODE_FLAT, false, false>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
     }
     if (e != hipSuccess || n_chunks <= 1u) return e;
     const uint32_t n_floats = width * height * 3u;
@@ -347,13 +348,10 @@ template <int MODE, bool COUNT>
 static hipError_t launch_trace_variant(const SceneDev& S, const rrt_ray* d_rays, uint32_t n, float tmin, float tmax,
                                        rrt_hit* d_out, unsigned long long* d_counters, unsigned int* d_head, int cu_count,
                                        const RenderTuning& tuning, hipStream_t stream) {
-    static int blocks_per_cu = 0;  // per template instantiation
-    if (blocks_per_cu == 0) {
-        int k = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&k, k_trace_stream<MODE, COUNT>, RENDER_BLOCK, 0);
-        if (e != hipSuccess) return e;
-        blocks_per_cu = k > 0 ? k : 1;
-    }
+    static std::atomic<int> cache{0};  // per template instantiation
+    int blocks_per_cu = 1;
+    if (hipError_t e = resident_blocks_per_cu(k_trace_stream<MODE, COUNT>, cache, blocks_per_cu); e != hipSuccess) return e;
+    if (tuning.blocks_per_cu != 0u && (int)tuning.blocks_per_cu < blocks_per_cu) blocks_per_cu = (int)tuning.blocks_per_cu;
     unsigned long long blocks = (unsigned long long)blocks_per_cu * (unsigned)cu_count;
     const unsigned long long needed = ((unsigned long long)n + RENDER_BLOCK - 1ull) / RENDER_BLOCK;
     if (blocks > needed) blocks = needed;
@@ -367,7 +365,7 @@ hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, 
                             const RenderTuning& tuning, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const int mode = S.unroll_shift != 0u ? MODE_UNROLLED : (S.has_instances != 0u ? MODE_TWO_LEVEL : MODE_FLAT);
-    if (getenv("RRT_INTERSECT_STATIC")) {  // experiment knob: the plain one-lane-per-ray kernel
+    if (tuning.intersect_static != 0u) {  // experiment knob: the plain one-lane-per-ray kernel
         dim3 grid((unsigned)((n + WAVE - 1) / WAVE)), block(WAVE);
         if (mode == MODE_UNROLLED)
             hipLaunchKernelGGL((k_intersect<MODE_UNROLLED>), grid, block, 0, stream, S, d_rays, n, tmin, tmax, d_out);

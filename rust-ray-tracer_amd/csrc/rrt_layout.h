@@ -167,11 +167,13 @@ struct SceneDev {
 };
 
 // Launch geometry of the render kernel.  The frame is cut into 8x8 pixel tiles and the sample range into
-// `n_chunks` chunks of `chunk_spp` samples; one work item = (tile, chunk), item index = tile * n_chunks + chunk,
+// `n_chunks` (<= spp) chunks whose lengths differ by at most one: with q = spp / n_chunks and r = spp % n_chunks, chunk c
+// holds the q + (c < r) samples that start at sample c * q + min(c, r), so any sample count cuts into any number of
+// chunks without an empty or a short last one.  One work item = (tile, chunk), item index = tile * n_chunks + chunk,
 // so that the chunks of an expensive tile are handed out back to back and run on many CUs at the same time.
 struct RenderGeom {
     uint32_t width, height, spp, spp_offset;
-    uint32_t tiles_x, n_tiles, n_chunks, chunk_spp;
+    uint32_t tiles_x, n_tiles, n_chunks, chunk_q;
     // Tiles are numbered band by band: vertical bands of `band_tiles` tiles' width, row by row inside a band, so that
     // the items in flight at one time cover a compact block of the image instead of a strip of one tile's height.
     uint32_t band_tiles;        // width of a full band in tiles
@@ -183,7 +185,11 @@ struct RenderGeom {
     uint32_t leave_ready;       // ... and at least this many lanes wait to shade (leave_walk 0: walk to the end)
     uint32_t n_groups;          // work items per tile (pipelined form: an item holds several consecutive chunks of its pixels)
     uint32_t pix_log2, tw_log2; // pipelined form: an item is 2^pix_log2 pixels (a tile 2^tw_log2 pixels wide) x 64 / pixels chunks
+    uint32_t chunk_r;           // the first chunk_r chunks hold chunk_q + 1 samples, the others chunk_q
 };
+// First sample (relative to the launch's first) and length of chunk c of a launch cut as RenderGeom describes.
+RRT_HD static inline uint32_t chunk_first(uint32_t c, uint32_t q, uint32_t r) { return c * q + (c < r ? c : r); }
+RRT_HD static inline uint32_t chunk_len(uint32_t c, uint32_t q, uint32_t r) { return q + (c < r ? 1u : 0u); }
 
 // Per-lane traversal stack entries (LDS).  One inner-node step pushes at most one entry, so the stack never
 // holds more than (tree depth) entries plus the bottom marker and, for instanced scenes, one exit marker;

@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "rrt_device.h"
@@ -195,9 +196,9 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 y = ty * TILE_H + (lane >> RRT_TILE_W_LOG2);
                 inside = x < width && y < height;
             }
-            // samples [first, first + spp) of this chunk, as absolute sample indices
-            const uint32_t first = chunk * G.chunk_spp;
-            const uint32_t spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
+            // samples [first, first + spp) of this chunk, relative to the launch's first sample
+            const uint32_t first = chunk_first(chunk, G.chunk_q, G.chunk_r);
+            const uint32_t spp = chunk_len(chunk, G.chunk_q, G.chunk_r);  // (a lane whose chunk does not exist is not `inside`)
             const uint32_t spp_offset = G.spp_offset + first;
             const uint32_t pixel = y * width + x;
 
@@ -318,10 +319,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
         };
         auto draw_into = [&](uint32_t slot) -> bool {
             const uint32_t work = draw();
-            // record: x0, y0, first chunk, samples of a full chunk (one chunk per item: of this chunk), first sample
-            // index of the first chunk, pixel permutation, chunks of the item that exist, samples of the last of them
+            // record: x0, y0, first chunk, samples of a short chunk (one chunk per item: of this chunk), first sample
+            // index of the first chunk, pixel permutation, chunks of the item that exist, how many of them (the item's
+            // first ones) hold one sample more
             uint32_t x0 = 0u, y0 = 0u, chunk = 0u, n_spp = 0u, first_sample = 0u;
-            [[maybe_unused]] uint32_t n_valid = 0u, n_last = 0u;
+            [[maybe_unused]] uint32_t n_valid = 0u, n_long = 0u;
             if (work != NO_WORK) {
                 if constexpr (SPLIT) {
                     const uint32_t tile = work / G.n_groups;
@@ -330,27 +332,25 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                     tile_coords(G, tile, tx, ty);
                     x0 = tx << tw_log2;
                     y0 = ty << (pix_log2 - tw_log2);
-                    n_spp = G.chunk_spp;
-                    first_sample = G.spp_offset + chunk * G.chunk_spp;
+                    n_spp = G.chunk_q;
+                    first_sample = G.spp_offset + chunk_first(chunk, G.chunk_q, G.chunk_r);
                     n_valid = min(64u >> pix_log2, G.n_chunks - chunk);
-                    const uint32_t last_first = (chunk + n_valid - 1u) * G.chunk_spp;
-                    n_last = last_first < G.spp ? min(G.chunk_spp, G.spp - last_first) : 0u;
+                    n_long = min(n_valid, G.chunk_r - min(chunk, G.chunk_r));
                 } else {
                     const uint32_t tile = work / G.n_chunks;
                     chunk = work % G.n_chunks;
-                    const uint32_t first = chunk * G.chunk_spp;  // samples [first, first + n_spp) as absolute sample indices
                     uint32_t tx, ty;
                     tile_coords(G, tile, tx, ty);
                     x0 = tx * TILE_W;
                     y0 = ty * TILE_H;
-                    n_spp = first < G.spp ? min(G.chunk_spp, G.spp - first) : 0u;
-                    first_sample = G.spp_offset + first;
+                    n_spp = chunk_len(chunk, G.chunk_q, G.chunk_r);
+                    first_sample = G.spp_offset + chunk_first(chunk, G.chunk_q, G.chunk_r);
                 }
             }
             if (lane == 0u) {
                 uint32_t* rec = items + slot * 8u;
                 rec[0] = x0; rec[1] = y0; rec[2] = chunk; rec[3] = n_spp; rec[4] = first_sample; rec[5] = flip;
-                if constexpr (SPLIT) { rec[6] = n_valid; rec[7] = n_last; }
+                if constexpr (SPLIT) { rec[6] = n_valid; rec[7] = n_long; }
             }
             flip ^= (uint32_t)RRT_LANE_FLIP;
             return work != NO_WORK;
@@ -486,11 +486,11 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         [[maybe_unused]] uint32_t first_sample = 0u;
                         if constexpr (SPLIT) {
                             // the lane's chunk of the pixel: the item's first chunk + the lane's group
-                            const uint32_t pix = pl & ((1u << pix_log2) - 1u), sub = pl >> pix_log2, n_valid = rec[6];
+                            const uint32_t pix = pl & ((1u << pix_log2) - 1u), sub = pl >> pix_log2, n_valid = rec[6], n_long = rec[7];
                             px_x = rec[0] + (pix & ((1u << tw_log2) - 1u));
                             px_y = rec[1] + (pix >> tw_log2);
-                            first_sample = rec[4] + sub * n_spp;
-                            n_spp = sub + 1u < n_valid ? n_spp : (sub + 1u == n_valid ? rec[7] : 0u);
+                            first_sample = rec[4] + sub * n_spp + min(sub, n_long);
+                            n_spp = sub < n_valid ? n_spp + (sub < n_long ? 1u : 0u) : 0u;
                         } else {
                             px_x = rec[0] + (pl & (TILE_W - 1u));
                             px_y = rec[1] + (pl >> RRT_TILE_W_LOG2);
@@ -540,22 +540,30 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
     if (lane == 0) atomicAdd(&counters[0], rays);
 }
 
+// Workgroups of `kernel` a CU holds at once, asked of the runtime once per kernel and kept in `cache` (one per template
+// instantiation; threads that race on the first call all store the same value).
+template <typename Kernel>
+static hipError_t resident_blocks_per_cu(Kernel kernel, std::atomic<int>& cache, int& out) {
+    int n = cache.load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, RENDER_BLOCK, 0);
+        if (e != hipSuccess) return e;
+        n = n > 0 ? n : 1;
+        cache.store(n, std::memory_order_relaxed);
+    }
+    out = n;
+    return hipSuccess;
+}
+
+// max_blocks_per_cu: 0, or fewer resident workgroups per CU than the kernel allows (RenderTuning::blocks_per_cu).
 template <int MODE, bool COUNT, bool PIPELINED, bool SCALED = false, bool SPLIT = false>
 static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, float* out, unsigned long long* d_counters,
-                                        unsigned int* d_heads, int cu_count, hipStream_t stream) {
+                                        unsigned int* d_heads, int cu_count, uint32_t max_blocks_per_cu, hipStream_t stream) {
     // persistent grid: as many workgroups as the chip holds at once (never more than there are work items)
-    static int blocks_per_cu = 0;  // per template instantiation
-    if (blocks_per_cu == 0) {
-        int n = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT>, RENDER_BLOCK, 0);
-        if (e != hipSuccess) return e;
-        blocks_per_cu = n > 0 ? n : 1;
-        // experiment knob: fewer resident workgroups per CU (occupancy sensitivity)
-        if (const char* env = getenv("RRT_BLOCKS_PER_CU")) {
-            const int v = atoi(env);
-            if (v > 0 && v < blocks_per_cu) blocks_per_cu = v;
-        }
-    }
+    static std::atomic<int> cache{0};
+    int blocks_per_cu = 1;
+    if (hipError_t e = resident_blocks_per_cu(k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT>, cache, blocks_per_cu); e != hipSuccess) return e;
+    if (max_blocks_per_cu != 0u && (int)max_blocks_per_cu < blocks_per_cu) blocks_per_cu = (int)max_blocks_per_cu;
     unsigned long long blocks = (unsigned long long)blocks_per_cu * (unsigned)cu_count;
     const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;
     if (blocks > needed) blocks = needed;
@@ -566,7 +574,8 @@ static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, 
 
 // The instantiations for unrolled scenes (rrt_kernels_unrolled.hip).
 hipError_t launch_render_unrolled(bool count_visits, bool pipelined, bool scaled, const SceneDev& S, const RenderGeom& G, float* out,
-                                  unsigned long long* d_counters, unsigned int* d_heads, int cu_count, hipStream_t stream);
+                                  unsigned long long* d_counters, unsigned int* d_heads, int cu_count, uint32_t max_blocks_per_cu,
+                                  hipStream_t stream);
 
 }  // namespace rrt
 #endif

@@ -87,15 +87,16 @@ struct Expander {
         uint32_t depth;
         float mn[3], mx[3];
         Grid grid;
-        // for unrolling (instances written out as world-space trees over the mesh's leaves): the triangle leaves of
-        // the host-built tree (reference words: count and first record), its node count and depth budget, the mesh's
-        // range of the leaf-ordered records, and whether the mesh holds triangles only
+        // for unrolling (instances written out as world-space trees over the mesh's leaves): the leaves of the
+        // host-built tree (reference words: kind, count and first record), its node count and depth budget, and the
+        // mesh's range of the leaf-ordered triangle records
         std::vector<uint32_t> leaves;
         uint32_t node_count = 0, budget = 0;
         uint32_t tri_base = 0, tri_count = 0;
-        bool tri_only = false, host_built = false;
+        bool host_built = false;
     };
-    // Unrolled scenes: world box of each instance's triangles (indexed like d->instances), computed before the world
+    // Unrolled scenes: world box of the primitives of each instance OBJECT of the world list (indexed like hs->insts:
+    // one record per object, in world order -- two objects may name the same rrt_instance), computed before the world
     // list is expanded; empty when the scene is not unrolled.
     std::vector<std::array<float, 6>> inst_world_box;
     std::vector<uint32_t> inst_of_record;  // per InstRec pushed: the index of its rrt_instance
@@ -249,8 +250,9 @@ struct Expander {
                     id += mi.prim_count;
                     BuildPrim p;
                     for (int a = 0; a < 3; ++a) { p.bmin[a] = FLT_MAX; p.bmax[a] = -FLT_MAX; }
-                    if (!inst_world_box.empty()) {  // unrolled: the padded world box of the instance's own triangles
-                        for (int a = 0; a < 3; ++a) { p.bmin[a] = inst_world_box[ob.first][a]; p.bmax[a] = inst_world_box[ob.first][3 + a]; }
+                    if (!inst_world_box.empty()) {  // unrolled: the padded world box of the instance's own primitives
+                        const std::array<float, 6>& wb = inst_world_box[hs->insts.size()];
+                        for (int a = 0; a < 3; ++a) { p.bmin[a] = wb[a]; p.bmax[a] = wb[3 + a]; }
                     } else
                     for (int c = 0; c < 8; ++c) {  // world box of the rotated + translated mesh box
                         const float x = (c & 1) ? mi.mx[0] : mi.mn[0];
@@ -366,21 +368,60 @@ static void world_tri_box(const TriRec& r, const rrt_instance& in, float pad, fl
     }
 }
 
-// The tree of one instance: `leaves` are the mesh's triangle leaves (reference words: count and first record);
-// `prims` receives one primitive per leaf with the world box of its triangles (also the instance's world box, in
-// mn/mx).  `rec(i)`: triangle record i of the scene's leaf-ordered record array.
+// The same for the other primitives a mesh may hold.  A sphere stays a sphere under the instance's rotation: its world
+// box is the mapped centre +- |radius| (sphere.rs:128-133).  A rectangle's world box is the box of the eight mapped
+// corners of its object-space box, the reference's 1e-4 on the thin axis included (aarect.rs:60-66,115-121,191-197: the
+// accepted point's coordinate on that axis is o + t * d, rounded, not k itself).
+static void world_box_of_corners(const double* lo_o, const double* hi_o, const rrt_instance& in, float pad, float* mn, float* mx) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int c = 0; c < 8; ++c) {
+        const double p[3] = {(c & 1) ? hi_o[0] : lo_o[0], (c & 2) ? hi_o[1] : lo_o[1], (c & 4) ? hi_o[2] : lo_o[2]};
+        const double w[3] = {(double)in.cos_theta * p[0] + (double)in.sin_theta * p[2] + (double)in.offset[0], p[1] + (double)in.offset[1],
+                             -(double)in.sin_theta * p[0] + (double)in.cos_theta * p[2] + (double)in.offset[2]};
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], w[a]); hi[a] = std::max(hi[a], w[a]); }
+    }
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = std::nextafterf((float)lo[a], -INFINITY) - pad;
+        mx[a] = std::nextafterf((float)hi[a], INFINITY) + pad;
+    }
+}
+static void world_sphere_box(const SphereRec& r, const rrt_instance& in, float pad, float* mn, float* mx) {
+    const double c[3] = {r.c[0], r.c[1], r.c[2]};
+    const double w[3] = {(double)in.cos_theta * c[0] + (double)in.sin_theta * c[2] + (double)in.offset[0], c[1] + (double)in.offset[1],
+                         -(double)in.sin_theta * c[0] + (double)in.cos_theta * c[2] + (double)in.offset[2]};
+    const double ar = std::fabs((double)r.r) * (1.0 + 1e-6);
+    for (int a = 0; a < 3; ++a) {
+        mn[a] = std::nextafterf((float)(w[a] - ar), -INFINITY) - pad;
+        mx[a] = std::nextafterf((float)(w[a] + ar), INFINITY) + pad;
+    }
+}
+static void world_rect_box(const RectRec& r, const rrt_instance& in, float pad, float* mn, float* mx) {
+    const uint32_t axis = r.axis_flags & 3u, ia = axis == 0 ? 1u : 0u, ib = axis == 2 ? 1u : 2u;
+    double lo[3], hi[3];
+    lo[axis] = (double)r.k - 0.0001; hi[axis] = (double)r.k + 0.0001;
+    lo[ia] = std::min(r.a0, r.a1); hi[ia] = std::max(r.a0, r.a1);
+    lo[ib] = std::min(r.b0, r.b1); hi[ib] = std::max(r.b0, r.b1);
+    world_box_of_corners(lo, hi, in, pad, mn, mx);
+}
+
+// The tree of one instance: `leaves` are the mesh's leaves (reference words: kind, count and first record);
+// `prims` receives one primitive per leaf with the world box of what the leaf holds (also the instance's world box, in
+// mn/mx).  `rec(i)`: triangle record i of the scene's leaf-ordered record array; spheres and rectangles are read
+// from the host scene's record arrays.
 template <typename RecFn>
-static void instance_leaf_prims(const std::vector<uint32_t>& leaves, const rrt_instance& in, float pad, RecFn rec,
+static void instance_leaf_prims(const std::vector<uint32_t>& leaves, const rrt_instance& in, float pad, RecFn rec, const HostScene& hs,
                                 std::vector<BuildPrim>& prims, float* mn, float* mx) {
     prims.resize(leaves.size());
     for (int a = 0; a < 3; ++a) { mn[a] = FLT_MAX; mx[a] = -FLT_MAX; }
     for (size_t k = 0; k < leaves.size(); ++k) {
-        const uint32_t first = leaves[k] & REF_OFFSET_MASK, cnt = ((leaves[k] >> 25) & 7u) + 1u;
+        const uint32_t kind = (leaves[k] >> 28) & 7u, first = leaves[k] & REF_OFFSET_MASK, cnt = kind == KIND_TRI ? ((leaves[k] >> 25) & 7u) + 1u : 1u;
         BuildPrim& p = prims[k];
         for (int a = 0; a < 3; ++a) { p.bmin[a] = FLT_MAX; p.bmax[a] = -FLT_MAX; }
         for (uint32_t j = 0; j < cnt; ++j) {
             float tmn[3], tmx[3];
-            world_tri_box(rec(first + j), in, pad, tmn, tmx);
+            if (kind == KIND_TRI) world_tri_box(rec(first + j), in, pad, tmn, tmx);
+            else if (kind == KIND_SPHERE) world_sphere_box(hs.spheres[first], in, pad, tmn, tmx);
+            else world_rect_box(hs.rects[first], in, pad, tmn, tmx);
             for (int a = 0; a < 3; ++a) { p.bmin[a] = std::min(p.bmin[a], tmn[a]); p.bmax[a] = std::max(p.bmax[a], tmx[a]); }
         }
         p.kind = KIND_SUBTREE;
@@ -598,7 +639,6 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         }
         std::vector<BvhNode> built;
         meshes[mi].tri_base = (uint32_t)tri_order.size();
-        meshes[mi].tri_only = std::all_of(prims.begin(), prims.end(), [](const BuildPrim& p) { return p.kind == KIND_TRI; });
         BuildResult br = build_bvh(prims, built, tri_order, (uint32_t)tri_order.size(), budget, threads, (int64_t)hs.qnodes.size());
         meshes[mi].tri_count = (uint32_t)tri_order.size() - meshes[mi].tri_base;
         meshes[mi].grid = quantize_nodes(hs, built, br.root_min, br.root_max, threads);
@@ -608,7 +648,7 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
         meshes[mi].budget = budget;
         for (const BvhNode& nd : built)
             for (int32_t ref : {nd.left, nd.right})
-                if (ref < 0 && (((uint32_t)ref >> 28) & 7u) == KIND_TRI) meshes[mi].leaves.push_back((uint32_t)ref);
+                if (ref < 0 && (((uint32_t)ref >> 28) & 7u) <= KIND_RECT) meshes[mi].leaves.push_back((uint32_t)ref);  // triangles, a sphere, a rectangle
         meshes[mi].root = br.root;
         meshes[mi].prim_count = id;
         meshes[mi].depth = br.depth;
@@ -618,10 +658,11 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     }
 
     trace.mark("meshes");
-    // Unroll the instances into one world-space tree?  Only when every instanced mesh was built here and holds
-    // triangles only, the copies stay within a node budget (RRT_UNROLL_MAX_NODES, default 2^24 = 512 MB of nodes), and a
-    // triangle leaf's 25-bit field has room for (instance slot, first record).
+    // Unroll the instances into one world-space tree?  Only when every instanced mesh was built here, the copies stay
+    // within a node budget (RRT_UNROLL_MAX_NODES, default 2^24 = 512 MB of nodes), and a leaf's 25-bit field has room
+    // for (instance slot, first record) -- for triangle, sphere and rectangle records alike.
     uint32_t unroll_shift = 0;
+    std::vector<uint32_t> inst_objs;  // the rrt_instance of every instance object of the world list, in world order
     if (unroll && d->instance_count > 0u) {
         bool ok = true;
         uint64_t copy_nodes = 0, world_tris = 0;
@@ -630,21 +671,26 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
             if (ob.type == RRT_OBJ_TRIANGLES) world_tris += ob.count;
             if (ob.type != RRT_OBJ_INSTANCE) continue;
             if (ob.count != 1u || ob.first >= d->instance_count || d->instances[ob.first].mesh >= d->mesh_count) { ok = false; break; }  // reported by expand()
+            inst_objs.push_back(ob.first);
             const rrt_instance& in = d->instances[ob.first];
             const Expander::MeshInfo& mi = meshes[in.mesh];
             // (the world boxes take the instance's point map for the inverse of its ray map, which it is for a rotation:
             // an instance whose sin / cos pair is not one keeps the two-level walk, which makes no such assumption)
             const double norm = (double)in.sin_theta * in.sin_theta + (double)in.cos_theta * in.cos_theta;
-            ok = mi.host_built && mi.tri_only && mi.tri_count > 0u && std::fabs(norm - 1.0) < 1e-5;
+            ok = mi.host_built && !mi.leaves.empty() && std::fabs(norm - 1.0) < 1e-5;
             copy_nodes += mi.node_count;
         }
         uint64_t max_nodes = 1ull << 24;
         if (const char* e = std::getenv("RRT_UNROLL_MAX_NODES")) max_nodes = (uint64_t)std::max(0ll, std::atoll(e));
-        const uint64_t records = (uint64_t)tri_order.size() + world_tris + MAX_LEAF_TRIS;
+        // (spheres and rectangles: an upper bound on the records the world list and the meshes will have made)
+        uint64_t other_records = 0;
+        for (uint32_t i = 0; i < d->world_count; ++i) if (d->world[i].type != RRT_OBJ_TRIANGLES && d->world[i].type != RRT_OBJ_INSTANCE) other_records += d->world[i].type == RRT_OBJ_CUBOIDS ? 6ull * d->world[i].count : d->world[i].count;
+        for (uint32_t i = 0; i < d->mesh_object_count; ++i) if (d->mesh_objects[i].type != RRT_OBJ_TRIANGLES) other_records += d->mesh_objects[i].type == RRT_OBJ_CUBOIDS ? 6ull * d->mesh_objects[i].count : d->mesh_objects[i].count;
+        const uint64_t records = std::max((uint64_t)tri_order.size() + world_tris + MAX_LEAF_TRIS, other_records + 1u);
         uint32_t shift = 1;
         while ((1ull << shift) < records) ++shift;
         if (ok && copy_nodes > 0u && copy_nodes <= max_nodes && hs.qnodes.size() + copy_nodes + 2u * d->world_count + 64u < (uint64_t)REF_OFFSET_MASK &&
-            shift < 25u && (uint64_t)d->instance_count < (1ull << (25u - shift)))
+            shift < 25u && (uint64_t)inst_objs.size() < (1ull << (25u - shift)))  // slots 1 .. objects, slot 0 = not instanced
             unroll_shift = shift;
     }
     // per instance: one primitive per leaf of its mesh, with the world box of the leaf's triangles (kept for the build
@@ -652,20 +698,23 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
     std::vector<std::vector<BuildPrim>> inst_prims;
     auto rec_of = [&](uint32_t i) -> const TriRec& { return ex.tri_src[tri_order[i]]; };
     if (unroll_shift) {
-        ex.inst_world_box.resize(d->instance_count);
-        inst_prims.resize(d->instance_count);
+        // (per instance OBJECT, not per rrt_instance: the builds below reorder their primitives in place, and two
+        // objects that name the same instance each get a tree and a slot of their own)
+        const uint32_t n_objs = (uint32_t)inst_objs.size();
+        ex.inst_world_box.resize(n_objs);
+        inst_prims.resize(n_objs);
         std::vector<std::thread> pool;
         std::atomic<uint32_t> next{0};
         auto work = [&]() {
-            for (uint32_t i; (i = next.fetch_add(1)) < d->instance_count;) {
-                const rrt_instance& in = d->instances[i];
-                std::array<float, 6>& b = ex.inst_world_box[i];
+            for (uint32_t r; (r = next.fetch_add(1)) < n_objs;) {
+                const rrt_instance& in = d->instances[inst_objs[r]];
+                std::array<float, 6>& b = ex.inst_world_box[r];
                 b = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (in.mesh >= d->mesh_count || meshes[in.mesh].leaves.empty()) continue;
-                instance_leaf_prims(meshes[in.mesh].leaves, in, ex.pad, rec_of, inst_prims[i], b.data(), b.data() + 3);
+                if (meshes[in.mesh].leaves.empty()) continue;
+                instance_leaf_prims(meshes[in.mesh].leaves, in, ex.pad, rec_of, hs, inst_prims[r], b.data(), b.data() + 3);
             }
         };
-        for (unsigned t = 1; t < std::min<unsigned>(threads, d->instance_count); ++t) pool.emplace_back(work);
+        for (unsigned t = 1; t < std::min<unsigned>(threads, n_objs); ++t) pool.emplace_back(work);
         work();
         for (std::thread& t : pool) t.join();
         trace.mark("instance leaf boxes");
@@ -721,12 +770,12 @@ rrt_status build_host_scene(const rrt_scene_desc* d, HostScene& hs, std::string&
                 for (uint32_t r; (r = next.fetch_add(1)) < hs.insts.size();) {
                     const uint32_t i = ex.inst_of_record[r];
                     const Expander::MeshInfo& mi = meshes[d->instances[i].mesh];
-                    const uint32_t depth = build_instance_tree(inst_prims[i], mi.leaves, r + 1u, unroll_shift, copy_base[r], mi.node_count,
+                    const uint32_t depth = build_instance_tree(inst_prims[r], mi.leaves, r + 1u, unroll_shift, copy_base[r], mi.node_count,
                                                                mi.budget, hs.grid, hs.qnodes.data() + copy_base[r]);
                     if (depth == 0u || depth > mi.budget) failed.store(true);
                     uint32_t seen = deepest.load();
                     while (depth > seen && !deepest.compare_exchange_weak(seen, depth)) {}
-                    std::vector<BuildPrim>().swap(inst_prims[i]);
+                    std::vector<BuildPrim>().swap(inst_prims[r]);
                 }
             };
             for (unsigned t = 1; t < std::min<unsigned>(threads, (unsigned)hs.insts.size()); ++t) pool.emplace_back(work);

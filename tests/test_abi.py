@@ -28,23 +28,24 @@ def test_library_exports_every_declared_symbol(rrt):
     lib = rrt.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), f"librrt_hip.so does not export {name}"
-    assert lib.rrt_abi_version() == 2
+    assert lib.rrt_abi_version() == 3
 
 
 def test_header_compiles_as_c_and_pod_sizes_match(rrt, tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text(
         '#include <stdio.h>\n#include "rrt_ffi.h"\n'
-        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\","
+        "int main(void){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\","
         "sizeof(rrt_config),sizeof(rrt_material),sizeof(rrt_triangle),sizeof(rrt_sphere),sizeof(rrt_rect),"
         "sizeof(rrt_cuboid),sizeof(rrt_object),sizeof(rrt_mesh),sizeof(rrt_instance),sizeof(rrt_light),"
-        "sizeof(rrt_camera),sizeof(rrt_scene_desc),sizeof(rrt_ray),sizeof(rrt_hit),sizeof(rrt_stats));return 0;}\n")
+        "sizeof(rrt_camera),sizeof(rrt_scene_desc),sizeof(rrt_ray),sizeof(rrt_hit),sizeof(rrt_stats),sizeof(rrt_tuning),"
+        "sizeof(rrt_scene_info));return 0;}\n")
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(t) for t in (rrt.Config, rrt.MaterialPOD, rrt.TrianglePOD, rrt.SpherePOD, rrt.RectPOD, rrt.CuboidPOD,
                                   rrt.ObjectPOD, rrt.MeshPOD, rrt.InstancePOD, rrt.LightPOD, rrt.CameraPOD, rrt.SceneDescPOD,
-                                  rrt.RayPOD, rrt.HitPOD, rrt.Stats)]
+                                  rrt.RayPOD, rrt.HitPOD, rrt.Stats, rrt.Tuning, rrt.SceneInfo)]
     assert got == want
 
 

@@ -50,7 +50,7 @@ def test_golden_vectors(rrt, renderer_cache, golden_dir, name):
 
 
 def test_unrolled_and_two_level_instances_give_the_same_hits(rrt, oracle, renderer_cache, monkeypatch):
-    """Triangle-only instanced meshes are written out as world-space copies of their tree inside the top-level BVH by
+    """Instanced meshes are written out as world-space copies of their tree inside the top-level BVH by
     default; RRT_CFG_NO_UNROLL keeps the two-level walk of the reference (src/geometry/transform.rs:22-31,99-130).  Both
     run the same primitive tests on the same operands: records identical bit for bit, and equal to the oracle's."""
     r, scene = get(rrt, renderer_cache, "instanced_tris")
@@ -67,12 +67,55 @@ def test_unrolled_and_two_level_instances_give_the_same_hits(rrt, oracle, render
     # the plain one-lane-per-ray kernel (an experiment knob) walks the unrolled tree as well
     rays = helpers.primary_rays(o, 160, 90, 2048, seed=9)
     want = r.intersect(rays)
-    monkeypatch.setenv("RRT_INTERSECT_STATIC", "1")
+    r.set_tuning(intersect_static=1)
     assert np.array_equal(r.intersect(rays), want)
-    monkeypatch.delenv("RRT_INTERSECT_STATIC")
-    # a mesh that holds anything but triangles keeps the two-level form
-    r2, _ = get(rrt, renderer_cache, "instanced")
-    assert r2.info().unrolled_instances == 0
+    r.set_tuning(intersect_static=None)
+    # meshes that hold spheres and rectangles (the reference's own use: Translate(RotateY(Cuboid)), src/scene.rs:216-236)
+    # are unrolled the same way, their leaves naming the instance like triangle leaves do
+    for name, n_inst in (("instanced", 9), ("cornell", 2)):
+        r2, scene2 = get(rrt, renderer_cache, name)
+        assert r2.info().unrolled_instances == n_inst
+        two = rrt.Renderer(unroll_instances=False)
+        assert two.upload(scene2).unrolled_instances == 0
+        o2 = oracle.OracleScene(scene2)
+        for kind, rays in helpers.ray_suite(scene2, o2, n=4096, seed=6).items():
+            a, b = r2.intersect(rays), two.intersect(rays)
+            assert a.tobytes() == b.tobytes(), (name, kind)  # (bytes: a sphere's far-root uv is NaN on both sides)
+            helpers.assert_hits_match(a, o2.intersect(rays))
+        two.close()
+
+
+def test_an_instance_listed_twice_gets_two_trees(rrt, oracle):
+    """Two world objects that name the same rrt_instance: ids, tree and instance slot per object, hits and image as the
+    two-level form and the oracle give them."""
+    from rust_ray_tracer_amd import scenes
+
+    s = rrt.Scene()
+    m = s.add_material(rrt.Lambertian(0.6, 0.6, 0.6))
+    light = s.add_material(rrt.DiffuseLight(100.0, 100.0, 100.0))
+    mesh = s.new_mesh()
+    s.add_triangles(scenes.blob_mesh(8, 9, 0.6, 0.3, seed=1), m, mesh=mesh)
+    s.add_sphere((0.0, 0.9, 0.0), 0.2, m, mesh=mesh)
+    mi = s.finish_mesh(mesh)
+    s.add_instance(mi, angle_deg=30.0, offset=(1.0, 0.0, 0.0))
+    s.world.append((rrt.OBJ_INSTANCE, 0, 1))
+    s.add_instance(mi, angle_deg=-50.0, offset=(-1.5, 0.2, 0.3))
+    s.world.append((rrt.OBJ_INSTANCE, 0, 1))
+    s.add_sphere((0.0, 5.0, 0.0), 0.5, light)
+    s.add_sphere_light((0.0, 5.0, 0.0), 0.5)
+    s.camera = rrt.Camera(16.0 / 9.0, 45.0, scenes.look_at_c2w((0.0, 2.0, 6.0), (0.0, 0.0, 0.0)))
+    a, b = rrt.Renderer(seed=3), rrt.Renderer(seed=3, unroll_instances=False)
+    assert a.upload(s).unrolled_instances == 4 and b.upload(s).unrolled_instances == 0
+    o = oracle.OracleScene(s)
+    for kind, rays in helpers.ray_suite(s, o, n=2048, seed=8).items():
+        ga, gb = a.intersect(rays), b.intersect(rays)
+        assert ga.tobytes() == gb.tobytes(), kind
+        helpers.assert_hits_match(ga, o.intersect(rays))
+    ia, sa = a.render(96, 54, 4)
+    ib, sb = b.render(96, 54, 4)
+    assert sa.rays == sb.rays and np.array_equal(ia, ib)
+    a.close()
+    b.close()
 
 
 def test_t_range_arguments(rrt, oracle, renderer_cache):
@@ -203,14 +246,14 @@ def test_streaming_batch_sizes_order_and_counters(rrt, oracle, renderer_cache, m
     ref = np.tile(r.intersect(base), 700)[: len(big)]
     assert np.array_equal(got, ref)
     # refill threshold 1 (every idle lane refills at once) and 64 (a wave only refills when it is empty)
-    for thr in ("1", "64"):
-        monkeypatch.setenv("RRT_REFILL_MIN", thr)
+    for thr in (1, 64):
+        r.set_tuning(refill_min=thr)
         assert np.array_equal(r.intersect(base), ref[: len(base)])
-    monkeypatch.delenv("RRT_REFILL_MIN")
+    r.set_tuning(refill_min=None)
     # the plain one-lane-per-ray kernel is the same function of the rays
-    monkeypatch.setenv("RRT_INTERSECT_STATIC", "1")
+    r.set_tuning(intersect_static=1)
     assert np.array_equal(r.intersect(base), ref[: len(base)])
-    monkeypatch.delenv("RRT_INTERSECT_STATIC")
+    r.set_tuning(intersect_static=None)
     # counting variant: same hits, counters consistent with the walk
     rc = rrt.Renderer(count_visits=True)
     rc.upload(scene)
@@ -297,7 +340,7 @@ def test_unrolled_scene_with_more_instances_than_the_kernels_keep_in_lds(rrt, or
 
 
 def test_unrolled_instances_with_hostile_coordinates(rrt, oracle):
-    """Unrolled instances put world-space boxes around triangles that are tested in object space, with the ray moved
+    """Unrolled instances put world-space boxes around primitives that are tested in object space, with the ray moved
     there in f32: the boxes' pad has to cover the rounding of that move.  Small meshes far from the origin, far from
     each other and rotated by awkward angles, rays from inside, from far outside and along the axes; the two-level
     form on the same rays must give the same records, and both the oracle's."""
@@ -310,6 +353,10 @@ def test_unrolled_instances_with_hostile_coordinates(rrt, oracle):
         centres = g.uniform(-1, 1, (n, 1, 3)) * scale
         tris = (centres + g.normal(0, 0.05 * scale, (n, 3, 3))).astype(np.float32)
         s.add_triangles(tris, m, mesh=mesh)
+        # ... and the other primitives a mesh may hold: their leaves are unrolled the same way
+        s.add_sphere((0.3 * scale, -0.2 * scale, 0.1 * scale), 0.4 * scale, m, mesh=mesh)
+        s.add_cuboid((-1.2 * scale, -1.2 * scale, -1.2 * scale), (-0.6 * scale, 0.9 * scale, -0.8 * scale), m, mesh=mesh)
+        s.add_rect(1, -scale, scale, -scale, scale, -1.3 * scale, m, mesh=mesh)
         mi = s.finish_mesh(mesh)
         offsets = g.uniform(-1, 1, (10, 3)) * spread
         angles = [0.0, 90.0, 180.0, 270.0, 45.0, 1e-3, 359.999, 33.3, 123.4, 271.7]
@@ -332,8 +379,9 @@ def test_unrolled_instances_with_hostile_coordinates(rrt, oracle):
         rays = helpers.make_rays(origins.astype(np.float32), dirs.astype(np.float32))
         ga, gb, want = a.intersect(rays, t_min=1e-4 * scale), b.intersect(rays, t_min=1e-4 * scale), oracle.OracleScene(s).intersect(rays, t_min=1e-4 * scale)
         assert (want["prim_id"] >= 0).mean() > 0.02, (scale, spread)
-        assert np.array_equal(ga, gb), (scale, spread)
+        assert ga.tobytes() == gb.tobytes(), (scale, spread)
         helpers.assert_hits_match(ga, want)
+        assert np.isin(want["prim_id"] % (n + 8), np.arange(n, n + 8)).sum() > 20  # spheres / rectangles of the instances are hit
         a.close()
         b.close()
 
