@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame-check", action="store_true", help="skip the untimed comparison of the frame with its whole-tile rendering")
     ap.add_argument("--device-build", action="store_true", help="build large BVHs on the GPU (linear BVH) instead of the host's SAH build")
     return ap.parse_args()
 
@@ -97,6 +98,17 @@ def build_scene(rrt, config: int):
     raise SystemExit(f"unknown config {config}")
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(scene, width, height, spp_full, seed, mode_name, budget_s=30.0):
     """Times the CPU restatement (reference-style pointer BVH, recursive ray_color, row-parallel threads) on a bounded
     sample of the same workload: the same camera frame at a lower resolution and sample count (the same mix of rays).
@@ -129,7 +141,7 @@ def cpu_baseline(scene, width, height, spp_full, seed, mode_name, budget_s=30.0)
         _, rays = o.render(sw, sh, spp, mode=mode, threads=threads, seed=seed)
         dt = time.perf_counter() - t0
     box = ("the reference's per-axis box test" if mode_name == "reference" else "running-interval slab test (NOT the reference's)") if mode != oracle.HIT_BRUTE else "no boxes"
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "host_cpus": os.cpu_count(),
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
             "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"), "kind": "port",
             "sample": f"the frame at {sw}x{sh} (full: {width}x{height}), {spp} of {spp_full} spp: {rays} rays in {dt:.1f} s; {tree}, {box}",
             "samples_per_s": sw * sh * spp / dt, "rays": rays, "seconds": dt}
@@ -220,6 +232,24 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    # One more untimed step on rank 0: the frame as the timed steps render it (on scenes without instances: work items of
+    # a few pixels x many sample chunks) against the same sample slice rendered with whole 8x8 tiles as items.  Every
+    # pixel's chunk sums are formed by one lane in sample order either way, so the two must agree in every bit and in
+    # the number of rays; a difference ends the benchmark.
+    frame_check = None
+    if rank == 0 and not args.no_frame_check:
+        renderer.render_device(width, height, spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
+        st_a = renderer.render_stats()
+        whole = torch.empty_like(accum)
+        renderer.set_tuning(chunks=st_a.chunks, split_items=0)
+        renderer.render_device(width, height, spp, spp_offset, whole.data_ptr(), stream.cuda_stream)
+        st_b = renderer.render_stats()
+        renderer.set_tuning(chunks=None, split_items=None)
+        same = bool(torch.equal(accum, whole)) and st_a.rays == st_b.rays and bool(torch.isfinite(accum).all())
+        del whole
+        if not same:
+            raise SystemExit("bench.py: the timed kernel variant and the whole-tile form of the kernel disagree on this frame")
+        frame_check = f"bit-identical to whole-tile items ({st_a.chunks} sample chunks, {st_a.rays} rays)"
     if grouped:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -317,8 +347,10 @@ def main():
             roof.update({"bound": "issue", "achieved": None, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,
                          "traffic": None, "note": "this scene / frame size has no committed PMC profile (profiles/pmc_per_launch.json)"})
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(scene, width, height, spp_total, args.seed, "reference")
-            cpu_sound = cpu_baseline(scene, width, height, spp_total, args.seed, "running_slab")
+            # the reference's box test hardly culls, so its sample is bounded by time (45 s); the sound hierarchy's
+            # sample is millions of rays in 15 s
+            cpu = cpu_baseline(scene, width, height, spp_total, args.seed, "reference", budget_s=45.0)
+            cpu_sound = cpu_baseline(scene, width, height, spp_total, args.seed, "running_slab", budget_s=15.0)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -336,6 +368,7 @@ def main():
                        "scene_bytes": info.device_bytes, "bvh_build_ms": info.build_ms,
                        "bvh_builder": "gpu linear BVH" if info.device_built else "host binned SAH",
                        "partition": "spp slices per GPU + RCCL reduce(sum) to rank 0"},
+            "frame_check": frame_check,
             "samples_per_s": samples_all * args.steps / elapsed,
             "rays_per_sample": rays_all / samples_all,
             "roofline": roof,

@@ -32,6 +32,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert roof["kernel"] == "k_render" and roof["bound"] in ("issue", "hbm")
     assert roof["frac"] is None or 0 < roof["frac"] <= 1.0  # never a fraction above one
     assert 0 < roof["lane_util_node"] <= 1 and roof["rays_per_launch"] > 0
+    assert out["frame_check"].startswith("bit-identical to whole-tile items")  # the bench checked the frame it times
 
 
 def test_two_ranks_launch_themselves_and_share_the_sample_range():

@@ -1,7 +1,9 @@
 """The multi-GPU partition through the C ABI (rrt_group_*): one process, one context per listed device, sample slices
-side by side, sum on member 0.  The GPU box has one GPU, so the members share it (the copy-and-add form of the sum; the
-RCCL form needs distinct GPUs and has not run on hardware): what is checked is the partition arithmetic, the sum and
-the stream / event ordering between members."""
+side by side, sum on member 0.  The GPU box has one GPU, so groups of several members share it (the copy-and-add form
+of the sum); the RCCL form of the sum needs distinct GPUs and runs here as a group of ONE member that is told to go
+through RCCL all the same (RRT_CFG_GROUP_FORCE_RCCL): communicator set-up, the grouped in-place ncclReduce to member 0
+and its ordering behind the render on the member's stream all execute; what a one-GPU box cannot run is the transport
+between GPUs.  Checked: the partition arithmetic, the sums, the stream / event ordering between members."""
 import numpy as np
 import pytest
 
@@ -56,6 +58,28 @@ def test_uneven_split_idle_members_and_a_group_of_one(rrt):
     assert np.array_equal(one, ref) and s1.rays == sr.rays
     g1.close()
     single.close()
+
+
+def test_a_group_of_one_can_be_made_to_sum_through_rccl(rrt):
+    scene = helpers.scene_mixed(rrt)
+    single = rrt.Renderer(device=0, seed=5)
+    single.upload(scene)
+    g = rrt.RendererGroup([0], seed=5, force_rccl=True)
+    assert g.size == 1 and g.reduce_path == "rccl"
+    g.upload(scene)
+    # twice per frame size (communicator, buffers and streams are reused), the second frame larger (buffers regrow)
+    for w, h, spp, off in ((120, 68, 16, 4), (120, 68, 16, 4), (333, 190, 24, 0), (333, 190, 24, 0)):
+        ref, sr = single.render(w, h, spp, off)
+        img, st = g.render(w, h, spp, off)
+        assert st.rays == sr.rays and st.samples == w * h * spp
+        assert np.array_equal(img, ref)  # the in-place reduce of one rank leaves the member's own image
+    assert np.array_equal(g.tonemap(img, 24), single.tonemap(ref, 24))
+    g.close()
+    single.close()
+    # the forced form needs distinct devices: RCCL refuses two ranks on one GPU
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.RendererGroup([0, 0], force_rccl=True)
+    assert "distinct" in str(e.value)
 
 
 def test_group_errors(rrt):

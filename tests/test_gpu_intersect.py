@@ -345,7 +345,7 @@ def test_unrolled_instances_with_hostile_coordinates(rrt, oracle):
     each other and rotated by awkward angles, rays from inside, from far outside and along the axes; the two-level
     form on the same rays must give the same records, and both the oracle's."""
     g = np.random.default_rng(77)
-    for scale, spread in ((1.0, 30.0), (0.05, 2000.0), (20.0, 1e4), (1e-2, 5.0)):
+    for scale, spread in ((1.0, 30.0), (0.05, 2000.0), (20.0, 1e4), (1e-2, 5.0), (3.0, 150.0)):
         s = rrt.Scene()
         m = s.add_material(rrt.Lambertian(0.5, 0.5, 0.5))
         mesh = s.new_mesh()
@@ -354,7 +354,13 @@ def test_unrolled_instances_with_hostile_coordinates(rrt, oracle):
         tris = (centres + g.normal(0, 0.05 * scale, (n, 3, 3))).astype(np.float32)
         s.add_triangles(tris, m, mesh=mesh)
         # ... and the other primitives a mesh may hold: their leaves are unrolled the same way
-        s.add_sphere((0.3 * scale, -0.2 * scale, 0.1 * scale), 0.4 * scale, m, mesh=mesh)
+        # (a sphere only where the reference's own test can see its radius: sphere.rs:56-58 forms |o - c|^2 - r^2 and
+        # b^2 - a c in f32, and from more than a few thousand radii away r^2 is below the rounding of |o - c|^2 -- the
+        # test's answer is then rounding noise, "hits" up to many radii beside the sphere included, which no box covers)
+        n_other = 7
+        if spread / scale <= 100.0:
+            s.add_sphere((0.3 * scale, -0.2 * scale, 0.1 * scale), 0.4 * scale, m, mesh=mesh)
+            n_other = 8
         s.add_cuboid((-1.2 * scale, -1.2 * scale, -1.2 * scale), (-0.6 * scale, 0.9 * scale, -0.8 * scale), m, mesh=mesh)
         s.add_rect(1, -scale, scale, -scale, scale, -1.3 * scale, m, mesh=mesh)
         mi = s.finish_mesh(mesh)
@@ -379,9 +385,12 @@ def test_unrolled_instances_with_hostile_coordinates(rrt, oracle):
         rays = helpers.make_rays(origins.astype(np.float32), dirs.astype(np.float32))
         ga, gb, want = a.intersect(rays, t_min=1e-4 * scale), b.intersect(rays, t_min=1e-4 * scale), oracle.OracleScene(s).intersect(rays, t_min=1e-4 * scale)
         assert (want["prim_id"] >= 0).mean() > 0.02, (scale, spread)
-        assert ga.tobytes() == gb.tobytes(), (scale, spread)
         helpers.assert_hits_match(ga, want)
-        assert np.isin(want["prim_id"] % (n + 8), np.arange(n, n + 8)).sum() > 20  # spheres / rectangles of the instances are hit
+        helpers.assert_hits_match(gb, want)
+        assert ga.tobytes() == gb.tobytes(), (scale, spread)
+        hit_ids = want["prim_id"][want["prim_id"] >= 0]
+        in_inst = hit_ids[hit_ids < 10 * (n + n_other)]
+        assert np.isin(in_inst % (n + n_other), np.arange(n, n + n_other)).sum() > 20  # spheres / rectangles of the instances are hit
         a.close()
         b.close()
 
