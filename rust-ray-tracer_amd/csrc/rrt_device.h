@@ -198,7 +198,8 @@ __device__ __forceinline__ bool better(const SceneDev& S, float t, uint32_t lid,
 
 // reference src/geometry/triangle.rs:38-69
 __device__ __forceinline__ void test_triangle(const SceneDev& S, uint32_t idx, V3 o, V3 d, float tmin, int32_t inst, Best& best) {
-    // 48-byte records at a 32-bit byte offset (two shifts) from the uniform base
+    // 48-byte records at a 32-bit byte offset from the uniform base
+    // (kept as the compiler's one 32-bit multiply: a 24-bit multiply or a shift and a shift-add measured no faster)
     const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tris) + ((idx << 5) + (idx << 4)));
     const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
     const V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q1.x, q1.y, q1.z), e2 = v3(q2.x, q2.y, q2.z);
@@ -426,6 +427,12 @@ __device__ __forceinline__ void slab_pair(uint32_t w, uint32_t rot, float a, flo
 // not the ray batches of rrt_intersect, whose kernels keep the convert form.  Either form only has to be conservative:
 // hits are decided by the primitive tests, so images do not depend on which one ran.
 static constexpr float SLAB_INV_MAX_SCALED = 0x1p78f;
+#ifndef RRT_NESTED_STEPS
+#define RRT_NESTED_STEPS 1  // 1: the steps of a group as nested conditions (one restore of the execution mask per group); 0: one condition per step
+#endif
+#ifndef RRT_SLAB_BFE
+#define RRT_SLAB_BFE 1  // 1: plane indices taken out of a node's dwords by bit-field extracts; 0: by a rotate, a mask and a shift
+#endif
 __device__ __forceinline__ float slab_rcp_scaled(float d) {
     return fmaxf(fminf(__builtin_amdgcn_rcpf(d), SLAB_INV_MAX_SCALED), -SLAB_INV_MAX_SCALED);
 }
@@ -437,9 +444,16 @@ __device__ __forceinline__ void trav_set_ray_scaled(Trav& T, V3 o, V3 d, const S
               ((S.grid.origin[2] - o.z) * S.sigma) * inv.z);
 }
 __device__ __forceinline__ void slab_pair_scaled(uint32_t w, uint32_t rot, float a, float b, float& t_in, float& t_out) {
+#if RRT_SLAB_BFE
+    // the half the ray enters through and the other one, each by one bit-field extract at a per-lane offset (two
+    // instructions per axis instead of a rotate, a mask and a shift)
+    t_in = __builtin_amdgcn_fmed3f(__builtin_fmaf(__uint_as_float(__builtin_amdgcn_ubfe(w, rot, 16u)), a, b), 0.0f, 1.0f);
+    t_out = __builtin_fmaf(__uint_as_float(__builtin_amdgcn_ubfe(w, rot ^ 16u, 16u)), a, b);
+#else
     const uint32_t v = __builtin_amdgcn_alignbit(w, w, rot);
     t_in = __builtin_amdgcn_fmed3f(__builtin_fmaf(__uint_as_float(v & 0xFFFFu), a, b), 0.0f, 1.0f);
     t_out = __builtin_fmaf(__uint_as_float(v >> 16), a, b);
+#endif
 }
 
 template <int MODE, bool SCALED = false>
@@ -602,11 +616,29 @@ __device__ __forceinline__ void trav_nodes(const SceneDev& S, V3& o, V3& d, floa
       }
       const bool window = K == 0 || (__builtin_amdgcn_ballot_w64(top + (STEPS - 1) * stride >= lim) & desc_m) == 0ull;
       if (__builtin_expect(window, 1)) {
+#if RRT_NESTED_STEPS
+          // the lanes of a group's later steps are a subset of those of its earlier ones: written as nested
+          // conditions, the group restores the execution mask once at its end instead of after every step
+          auto nest = [&](auto self, auto n) -> void {
+              constexpr int N = decltype(n)::value;
+              if constexpr (N > 0) {
+                  if (cur >= 0) {
+                      step(std::true_type{});
+                      self(self, std::integral_constant<int, N - 1>{});
+                  }
+              }
+          };
+          if (desc) {
+              step(std::true_type{});
+              nest(nest, std::integral_constant<int, STEPS - 1>{});
+          }
+#else
           if (desc) step(std::true_type{});
 #pragma unroll
           for (int extra = 1; extra < STEPS; ++extra) {
               if (cur >= 0) step(std::true_type{});
           }
+#endif
       } else {
           if (desc) step(std::false_type{});
 #pragma unroll
