@@ -570,15 +570,21 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     while (n_chunks > 1u && (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * n_chunks > 0x7FFFFFFFull) n_chunks /= 2u;
     // Split items hold a power of two of chunks side by side (launch_render): the power of two from 8 to 32 nearest (in
     // ratio, within a factor of two) to the count chosen above; whole tiles where there is none.  Chunk lengths differ
-    // by at most one sample (RenderGeom), so every sample count splits: 100 spp are 16 chunks of 6 or 7 samples.  (A
-    // chunk count the caller fixed is taken as it is.)
+    // by at most one sample (RenderGeom), so every sample count splits.  (A chunk count the caller fixed is taken as it
+    // is.)
+    // Where the chunks come out unequal and short, the lanes of an item differ by one sample in a few: the fewest
+    // chunks in range then (measured on MI355X, 1M-triangle scene at 4K: 100 spp in 8 chunks of 12 or 13 samples
+    // 122.4 ms, in 16 chunks of 6 or 7 126.0 ms, in 32 chunks 138.8 ms; whole tiles 123.1 ms).
     if (split_items && n_chunks > 1u && tn.chunks == RRT_TUNE_AUTO) {
-        uint32_t best = 0u;
+        uint32_t best = 0u, smallest = 0u;
         for (uint32_t p = 8u; p <= 32u; p *= 2u) {  // (items of 16 pixels and more are no better than whole tiles)
             if (p > spp || p > 2u * n_chunks || n_chunks > 2u * p) continue;
+            if (smallest == 0u) smallest = p;
+            if (spp % p != 0u && spp / p < 24u) continue;  // unequal and short
             // nearer to the chosen count in ratio; of two equally near ones the larger
             if (best == 0u || (p >= n_chunks ? (uint64_t)p * best <= (uint64_t)n_chunks * n_chunks : true)) best = p;
         }
+        if (best == 0u) best = smallest;
         if (best != 0u) n_chunks = best;
         else split_items = false;
     }
