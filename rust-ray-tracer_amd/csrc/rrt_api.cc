@@ -629,13 +629,17 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
         // bands of 64 tiles instead of 16 on frames of 8K width (measured on MI355X: the unrolled 10M-triangle scene in 159.9
         // instead of 162.8 ms, the flat one in 165.0 instead of 169.3; at 4K x 1024 spp 16 / 32 / 64 tiles take 1174 / 1182 /
         // 1195 ms, at 2560x1440 64 cost 1 %)
-        if (width >= 7000u) tuning.band_tiles = 64u;
+        // (round 3, after the node step got cheaper: 128 tiles render the flat 10M-triangle scene in 160.4 ms against 162.0)
+        if (width >= 7000u) tuning.band_tiles = huge_scene ? 128u : 64u;
     }
     tuning.split_items = split_items ? 1u : 0u;
     if (big_scene && huge_scene) {
         // the walks of multi-million-node scenes have longer tails: more stragglers are left behind per trip
         // (measured on MI355X, ten million triangles: 12 -> 20 is 1-2 % faster, flat and unrolled alike)
         tuning.leave_walk = 20u;
+        // ... and a node pass is worth keeping up a little longer (48 / 64 of the walkers descending instead of 40 / 64:
+        // 160.4 against 162.0 ms on the flat ten-million-triangle scene, no difference on the unrolled one)
+        tuning.node_share_64ths = 48u;
     }
     if (tn.node_share_64ths != RRT_TUNE_AUTO) tuning.node_share_64ths = tn.node_share_64ths;
     if (tn.leave_walk != RRT_TUNE_AUTO) tuning.leave_walk = tn.leave_walk;
