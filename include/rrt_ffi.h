@@ -219,7 +219,9 @@ typedef struct rrt_scene_info {
     uint32_t unrolled_instances; /* instances written out into the top-level BVH (0: none, or RRT_CFG_NO_UNROLL) */
     uint32_t scaled_slab;    /* 1: rrt_render walks this scene with the scaled form of the box arithmetic (one grid,
                                 camera ray directions between 2^-24 and 2^24 long); 0: with the convert form.  Same images. */
-    uint32_t reserved;
+    uint32_t pixel_list_permille; /* of the last render whose statistics were read and that collected per-pixel leaf
+                                lists for its primary rays: the share of the frame's pixels that got one, in 1/1000
+                                (0 before such a render).  The library uses it to decide whether collecting them pays. */
 } rrt_scene_info;
 
 /* ---- scheduling knobs (tests and experiments) ----  no counterpart in the reference.  How the render and ray-batch
@@ -227,7 +229,8 @@ typedef struct rrt_scene_info {
  * follows; `chunks` changes the order in which a pixel's partial sums are added (float rounding), every other knob
  * leaves images identical bit for bit.  RRT_TUNE_AUTO in a field = the library's own rule for the scene and frame.
  * rrt_create reads the environment ONCE (RRT_CHUNKS, RRT_SPLIT_ITEMS, RRT_NODE_SHARE, RRT_LEAVE_WALK, RRT_LEAVE_READY,
- * RRT_OVERLAP_ITEMS, RRT_BAND_TILES, RRT_SCALED_SLAB, RRT_REFILL_MIN, RRT_BLOCKS_PER_CU, RRT_INTERSECT_STATIC) into the
+ * RRT_OVERLAP_ITEMS, RRT_BAND_TILES, RRT_SCALED_SLAB, RRT_REFILL_MIN, RRT_BLOCKS_PER_CU, RRT_INTERSECT_STATIC, RRT_PIXEL_LISTS,
+ * RRT_PIXEL_LIST_LEN) into the
  * context's rrt_tuning; the render and intersect entry points never look at the environment.                      */
 #define RRT_TUNE_AUTO 0xFFFFFFFFu
 typedef struct rrt_tuning {
@@ -242,7 +245,9 @@ typedef struct rrt_tuning {
     uint32_t refill_min;       /* 1..64: idle lanes that make the ray-batch kernel draw new rays                        */
     uint32_t blocks_per_cu;    /* resident workgroups per CU of the persistent kernels (at most what the kernel allows) */
     uint32_t intersect_static; /* 1: rrt_intersect runs the plain one-lane-per-ray kernel                               */
-    uint32_t reserved[5];      /* RRT_TUNE_AUTO                                                                         */
+    uint32_t pixel_lists;      /* 1: primary rays of split items resolved against per-pixel leaf lists; 0: they walk    */
+    uint32_t pixel_list_len;   /* 1..11: a pixel whose camera rays can reach more leaves than this gets no list         */
+    uint32_t reserved[3];      /* RRT_TUNE_AUTO                                                                         */
 } rrt_tuning;
 
 /* ---- lifetime ----  replaces: process start-up in reference src/main.rs:26-56 */

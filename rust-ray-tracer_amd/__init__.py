@@ -130,14 +130,15 @@ class Tuning(C.Structure):
     _fields_ = [("chunks", C.c_uint32), ("split_items", C.c_uint32), ("node_share_64ths", C.c_uint32),
                 ("leave_walk", C.c_uint32), ("leave_ready", C.c_uint32), ("overlap_items", C.c_uint32),
                 ("band_tiles", C.c_uint32), ("scaled_slab", C.c_uint32), ("refill_min", C.c_uint32),
-                ("blocks_per_cu", C.c_uint32), ("intersect_static", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("blocks_per_cu", C.c_uint32), ("intersect_static", C.c_uint32), ("pixel_lists", C.c_uint32),
+                ("pixel_list_len", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class SceneInfo(C.Structure):
     _fields_ = [("prim_count", C.c_uint32), ("node_count", C.c_uint32), ("tri_count", C.c_uint32),
                 ("bvh_depth", C.c_uint32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
                 ("upload_ms", C.c_float), ("device_built", C.c_uint32), ("unrolled_instances", C.c_uint32),
-                ("scaled_slab", C.c_uint32), ("reserved", C.c_uint32)]
+                ("scaled_slab", C.c_uint32), ("pixel_list_permille", C.c_uint32)]
 
 
 class GltfOptions(C.Structure):

@@ -80,6 +80,8 @@ rrt_tuning tuning_from_env() {
     t.refill_min = env_u32("RRT_REFILL_MIN", 1u, 64u);
     t.blocks_per_cu = env_u32("RRT_BLOCKS_PER_CU", 1u, 64u);
     t.intersect_static = env_u32("RRT_INTERSECT_STATIC", 0u, 1u);
+    t.pixel_lists = env_u32("RRT_PIXEL_LISTS", 0u, 1u);
+    t.pixel_list_len = env_u32("RRT_PIXEL_LIST_LEN", 1u, PIXEL_LIST_MAX);
     for (uint32_t& r : t.reserved) r = RRT_TUNE_AUTO;
     return t;
 }
@@ -87,7 +89,7 @@ rrt_tuning clamp_tuning(rrt_tuning t) {
     auto cl = [](uint32_t& v, uint32_t lo, uint32_t hi) { if (v != RRT_TUNE_AUTO) v = std::max(lo, std::min(hi, v)); };
     cl(t.chunks, 1u, 0x7FFFFFFFu); cl(t.split_items, 0u, 1u); cl(t.node_share_64ths, 0u, 64u); cl(t.leave_walk, 0u, 63u);
     cl(t.leave_ready, 1u, 64u); cl(t.overlap_items, 0u, 1u); cl(t.band_tiles, 0u, 0x7FFFFFFFu); cl(t.scaled_slab, 0u, 1u);
-    cl(t.refill_min, 1u, 64u); cl(t.blocks_per_cu, 1u, 64u); cl(t.intersect_static, 0u, 1u);
+    cl(t.refill_min, 1u, 64u); cl(t.blocks_per_cu, 1u, 64u); cl(t.intersect_static, 0u, 1u); cl(t.pixel_lists, 0u, 1u); cl(t.pixel_list_len, 1u, PIXEL_LIST_MAX);
     for (uint32_t& r : t.reserved) r = RRT_TUNE_AUTO;
     return t;
 }
@@ -107,6 +109,8 @@ struct rrt_ctx {
     unsigned long long* d_counters = nullptr;  // 256 B: rays, node visits, primitive tests; work-queue heads at +64 B
     float* d_partial = nullptr;                // per-chunk partial images of the last render geometry (grown on demand)
     size_t partial_bytes = 0;
+    uint32_t* d_lists = nullptr;               // per-pixel candidate leaf lists of the last render geometry (grown on demand)
+    size_t lists_bytes = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     hipStream_t last_stream = nullptr;
     unsigned long long* last_counters = nullptr;  // the counter block the pending call used (d_counters, or the static one)
@@ -118,6 +122,10 @@ struct rrt_ctx {
     uint64_t pending_samples = 0;
     uint64_t pending_rays = 0;  // ray count of a pending ray batch (its kernel does not count rays itself)
     uint32_t pending_chunks = 0;  // sample chunks of the pending render
+    uint64_t pending_list_pixels = 0;  // pixels of the pending render if it collects per-pixel leaf lists, else 0
+    // share of the pixels that got a list in the last such render whose statistics were read (1.0: not known yet);
+    // reset by a scene upload
+    float list_share = 1.0f;
 };
 
 namespace {
@@ -300,6 +308,7 @@ void rrt_destroy(rrt_ctx* c) {
     free_scene(c);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_lists) (void)hipFree(c->d_lists);
     for (void* b : c->d_stage) if (b) (void)hipFree(b);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -423,6 +432,8 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
     c->info.device_bytes = total;
     c->info.build_ms = build_ms;
     c->info.upload_ms = upload_ms;
+    c->info.pixel_list_permille = 0u;
+    c->list_share = 1.0f;
     c->has_scene = true;
     return RRT_OK;
 }
@@ -505,6 +516,7 @@ rrt_status rrt_intersect_device(rrt_ctx* c, const rrt_ray* d_rays, size_t n, flo
     c->pending_samples = 0;
     c->pending_rays = n;
     c->pending_chunks = 0;
+    c->pending_list_pixels = 0;
     c->last_counters = c->d_counters;
     return RRT_OK;
 }
@@ -648,18 +660,40 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     if (tn.band_tiles != RRT_TUNE_AUTO) tuning.band_tiles = tn.band_tiles;
     if (tn.scaled_slab != RRT_TUNE_AUTO) tuning.scaled_slab = tn.scaled_slab;
     if (tn.blocks_per_cu != RRT_TUNE_AUTO) tuning.blocks_per_cu = tn.blocks_per_cu;
+    // Per-pixel candidate leaf lists for the primary rays (launch_render; split items in the pipelined form): collecting
+    // them costs about what one sample per pixel costs, and a listed pixel's samples then cost about a fifth less, so
+    // they pay from a few dozen samples of listed pixels on.  The share of pixels that get a list (fine geometry: few) is
+    // taken from the scene's last render whose statistics were read; until one was, every pixel is assumed to.
+    tuning.pixel_lists = tn.pixel_lists != RRT_TUNE_AUTO ? tn.pixel_lists : ((float)spp * c->list_share >= 32.0f ? 1u : 0u);
+    if (tn.pixel_list_len != RRT_TUNE_AUTO) tuning.pixel_list_len = tn.pixel_list_len;
+    // per-pixel candidate leaf lists for the primary rays (launch_render): a frame-sized buffer of the context, grown on
+    // demand; the entry point that may not allocate goes without them
+    uint32_t* d_lists = nullptr;
+    if (!noalloc && render_takes_pixel_lists(c->sdev, width, height, n_chunks, tuning)) {
+        const size_t lists_need = (size_t)pixels * PIXEL_LIST_DWORDS * sizeof(uint32_t);
+        if (lists_need > c->lists_bytes) {
+            RRT_HIP(c, hipDeviceSynchronize());
+            if (c->d_lists) (void)hipFree(c->d_lists);
+            c->d_lists = nullptr;
+            c->lists_bytes = 0;
+            RRT_HIP(c, hipMalloc((void**)&c->d_lists, lists_need));
+            c->lists_bytes = lists_need;
+        }
+        d_lists = c->d_lists;
+    }
     if (rrt_status st = order_after_pending(c, s)) return st;
     RRT_HIP(c, hipMemsetAsync(d_counters, 0, 256, s));
     RRT_HIP(c, hipEventRecord(c->ev_start, s));
     RRT_HIP(c, launch_render(c->sdev, width, height, spp, spp_offset, d_accum, d_partial, n_chunks, d_counters,
                              reinterpret_cast<unsigned int*>(d_counters + 8), c->cu_count,
-                             (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, tuning, s));
+                             (c->cfg.flags & RRT_CFG_COUNT_VISITS) != 0, tuning, s, d_lists));
     RRT_HIP(c, hipEventRecord(c->ev_stop, s));
     c->last_stream = s;
     c->render_pending = true;
     c->pending_samples = (uint64_t)width * height * spp;
     c->pending_rays = 0;
     c->pending_chunks = n_chunks;
+    c->pending_list_pixels = d_lists ? pixels : 0u;
     c->last_counters = d_counters;
     return RRT_OK;
 }
@@ -681,7 +715,7 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     if (!c->render_pending) return set_err(c, RRT_ERR_STATE, "rrt_render_stats: no render was issued");
     RRT_HIP(c, hipSetDevice(c->cfg.device));
     RRT_HIP(c, hipEventSynchronize(c->ev_stop));
-    unsigned long long h[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8..11] are the work-queue heads
+    unsigned long long h[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [8..11] are the work-queue heads
     RRT_HIP(c, hipMemcpy(h, c->last_counters ? c->last_counters : c->d_counters, sizeof h, hipMemcpyDeviceToHost));
     float ms = 0.f;
     RRT_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
@@ -698,6 +732,10 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     stats->samples = c->pending_samples;
     stats->kernel_ms = ms;
     stats->chunks = c->pending_chunks;
+    if (c->pending_list_pixels != 0u) {
+        c->list_share = (float)((double)h[14] / (double)c->pending_list_pixels);
+        c->info.pixel_list_permille = (uint32_t)(c->list_share * 1000.0f + 0.5f);
+    }
     return RRT_OK;
 }
 

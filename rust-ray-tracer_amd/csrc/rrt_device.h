@@ -331,6 +331,7 @@ __device__ __forceinline__ bool first_active_lane() {
 // The traversal stack is addressed as LDS (address space 3) throughout, so that every access is a ds_read / ds_write
 // and never a flat access through a generic pointer.
 typedef __attribute__((address_space(3))) int lds_int;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // How a kernel meets instanced meshes (template parameter MODE of the traversal functions):
 //   MODE_FLAT       the scene has no instances: one BVH.
@@ -841,6 +842,137 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, float x, float 
     const V3 ray_p = ((c0 * px + c1 * py) + c2 * (-1.0f)) + tr;  // Affine3A::transform_point3a
     o = v3(cam.origin[0], cam.origin[1], cam.origin[2]);
     d = ray_p - o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Candidate leaves of a pixel.  Every camera ray of one pixel (src/main.rs:92-94: the pixel's corner plus a jitter in
+// [0, 1)^2, through src/camera.rs:56-69, which is affine in the jittered coordinates) lies inside the pyramid spanned by
+// the rays through the pixel's four corners.  A leaf whose box that pyramid misses cannot hold a primitive any of those
+// rays hits (a hit point lies inside its primitive's box, which the leaf's stored box contains with the builder's
+// margin to spare), so the closest hit of a primary ray of the pixel is the minimum over the primitive tests of the
+// leaves the pyramid touches -- the same minimum the ray's own walk forms, found without a walk.  The render kernel
+// collects those leaves once per work item and pixel (frustum_leaves) and resolves the pixel's primary rays against
+// the list (test_listed_leaf).  Scenes without instances only.
+// ---------------------------------------------------------------------------------------------
+struct PixelFrustum {
+    V3 o;
+    V3 n[4];        // inward normals of the four side planes through o
+    V3 a;           // the ray through the pixel's centre
+    float inv_amax; // 1 / the largest a . d over the pyramid's rays d (attained at a corner: a . d is affine over the pixel)
+};
+__device__ __forceinline__ PixelFrustum pixel_frustum(const CameraRec& cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
+    // the jittered coordinates of the pixel lie in [px, px + 1] x [py, py + 1]; 1/64 of a pixel of slack on every side
+    // covers the rounding of the camera arithmetic many times over
+    const float e = 1.0f / 64.0f, x0 = (float)px - e, x1 = (float)px + 1.0f + e, y0 = (float)py - e, y1 = (float)py + 1.0f + e;
+    PixelFrustum F;
+    V3 d00, d10, d11, d01, o;
+    camera_ray(cam, x0, y0, w, h, F.o, d00);
+    camera_ray(cam, x1, y0, w, h, o, d10);
+    camera_ray(cam, x1, y1, w, h, o, d11);
+    camera_ray(cam, x0, y1, w, h, o, d01);
+    camera_ray(cam, (float)px + 0.5f, (float)py + 0.5f, w, h, o, F.a);
+    // (a side's normal from one corner direction and the DIFFERENCE to the next: the cross product of two nearly
+    // parallel vectors would cancel its leading digits)
+    F.n[0] = cross(d00, d10 - d00);
+    F.n[1] = cross(d10, d11 - d10);
+    F.n[2] = cross(d11, d01 - d11);
+    F.n[3] = cross(d01, d00 - d01);
+    for (int k = 0; k < 4; ++k)
+        if (dot(F.n[k], F.a) < 0.0f) F.n[k] = -F.n[k];
+    F.inv_amax = 1.0f / fmaxf(fmaxf(dot(F.a, d00), dot(F.a, d10)), fmaxf(dot(F.a, d11), dot(F.a, d01)));
+    return F;
+}
+// False only if the box [mn, mx] lies outside one of the pyramid's side planes (conservative: the plane test is made
+// at the box's corner furthest inside, with a relative allowance for the rounding of the sum).
+__device__ __forceinline__ bool frustum_touches_box(const PixelFrustum& F, V3 mn, V3 mx) {
+    bool in = true;
+    for (int k = 0; k < 4; ++k) {
+        const V3 n = F.n[k];
+        const V3 p = v3((n.x >= 0.0f ? mx.x : mn.x) - F.o.x, (n.y >= 0.0f ? mx.y : mn.y) - F.o.y, (n.z >= 0.0f ? mx.z : mn.z) - F.o.z);
+        const float a = n.x * p.x, b = n.y * p.y, c = n.z * p.z;
+        in = in && ((a + b) + c >= -4e-6f * ((fabsf(a) + fabsf(b)) + fabsf(c)));
+    }
+    return in;
+}
+// A lower bound of the ray parameter at which any ray of the pyramid can reach the box: a point q = o + t d has
+// a . (q - o) = t (a . d), so t >= min over the box of a . (q - o), divided by the largest a . d; a little below it, and
+// never below zero.
+__device__ __forceinline__ float frustum_box_entry(const PixelFrustum& F, V3 mn, V3 mx) {
+    const V3 a = F.a;
+    const V3 p = v3((a.x >= 0.0f ? mn.x : mx.x) - F.o.x, (a.y >= 0.0f ? mn.y : mx.y) - F.o.y, (a.z >= 0.0f ? mn.z : mx.z) - F.o.z);
+    const float x = a.x * p.x, y = a.y * p.y, z = a.z * p.z;
+    const float lo = ((x + y) + z) - 4e-6f * ((fabsf(x) + fabsf(y)) + fabsf(z));
+    return fmaxf(lo * F.inv_amax, 0.0f) * 0.9999f;
+}
+// Collects the leaves of the scene's (one) BVH whose stored boxes the pyramid touches, ordered by the lower bound of
+// the ray parameter at which a ray of the pixel can reach them: refs[i], entry[i] for i < the returned count, or
+// 0xFFFFFFFF when there are more than `max_len` (<= KMAX; the pixel's primary rays then walk the tree like every other
+// ray).  A plain depth-first walk on a private stack.
+template <int KMAX>
+__device__ __forceinline__ uint32_t frustum_leaves(const SceneDev& S, const PixelFrustum& F, uint32_t max_len, uint32_t* refs, float* entry) {
+    int todo[STACK_DEPTH];
+    float todo_t[STACK_DEPTH];
+    int sp = 0, cur = S.root;
+    float cur_t = 0.0f;
+    uint32_t n = 0u;
+    const V3 g0 = v3(S.grid.origin[0], S.grid.origin[1], S.grid.origin[2]), gs = v3(S.grid.step[0], S.grid.step[1], S.grid.step[2]);
+    for (;;) {
+        if (cur >= 0) {
+            const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
+            const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
+            auto lo = [&](uint32_t wx, uint32_t wy, uint32_t wz) {
+                return v3(__builtin_fmaf((float)(wx & 0xFFFFu), gs.x, g0.x), __builtin_fmaf((float)(wy & 0xFFFFu), gs.y, g0.y), __builtin_fmaf((float)(wz & 0xFFFFu), gs.z, g0.z));
+            };
+            auto hi = [&](uint32_t wx, uint32_t wy, uint32_t wz) {
+                return v3(__builtin_fmaf((float)(wx >> 16), gs.x, g0.x), __builtin_fmaf((float)(wy >> 16), gs.y, g0.y), __builtin_fmaf((float)(wz >> 16), gs.z, g0.z));
+            };
+            const V3 lmn = lo(a.z, a.w, b.x), lmx = hi(a.z, a.w, b.x), rmn = lo(b.y, b.z, b.w), rmx = hi(b.y, b.z, b.w);
+            const bool hl = frustum_touches_box(F, lmn, lmx), hr = frustum_touches_box(F, rmn, rmx);
+            const float tl = frustum_box_entry(F, lmn, lmx), tr = frustum_box_entry(F, rmn, rmx);
+            if (hl && hr) {
+                if (sp == STACK_DEPTH) return 0xFFFFFFFFu;  // (deeper than any tree the builders make)
+                todo[sp] = (int)a.y; todo_t[sp] = tr; sp++;
+                cur = (int)a.x; cur_t = tl;
+                continue;
+            }
+            if (hl || hr) {
+                cur = hl ? (int)a.x : (int)a.y; cur_t = hl ? tl : tr;
+                continue;
+            }
+        } else {
+            const uint32_t kind = ((uint32_t)cur >> 28) & 7u;
+            if (kind <= KIND_RECT) {  // triangles, a sphere, a rectangle (an empty child slot is skipped)
+                if (n == max_len) return 0xFFFFFFFFu;  // one more than a list may hold: no list, no point in going on
+                // insertion by entry bound (lists are a handful of entries long)
+                uint32_t k = n;
+                while (k > 0u && entry[k - 1u] > cur_t) { refs[k] = refs[k - 1u]; entry[k] = entry[k - 1u]; --k; }
+                refs[k] = (uint32_t)cur; entry[k] = cur_t;
+                n++;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = todo[sp]; cur_t = todo_t[sp];
+    }
+    return n;
+}
+// Tests the primitives of one listed leaf with the reference's arithmetic (what trav_leaf does for a walking lane).
+template <bool COUNT>
+__device__ __forceinline__ void test_listed_leaf(const SceneDev& S, uint32_t ref, V3 o, V3 d, float tmin, Best& best, TraceCounters& cnt) {
+    const uint32_t kind = (ref >> 28) & 7u, first = ref & REF_OFFSET_MASK;
+    if (kind == KIND_TRI) {
+        const uint32_t count = ((ref >> 25) & 7u) + 1u;
+        for (uint32_t j = 0; j < count; ++j) {
+            test_triangle(S, first + j, o, d, tmin, -1, best);
+            if (COUNT) cnt.prims++;
+        }
+    } else if (kind == KIND_SPHERE) {
+        test_sphere(S, first, o, d, tmin, -1, best);
+        if (COUNT) cnt.prims++;
+    } else {
+        test_rect(S, first, o, d, tmin, -1, best);
+        if (COUNT) cnt.prims++;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -46,14 +46,21 @@ struct RenderTuning {
     // Render kernel, scenes without instances: 1: a work item is a few pixels times as many of their sample chunks as make 64 lanes
     // (all of the frame's chunks when there are at most 32); 0: 64 pixels times one chunk.  Same image either way.
     uint32_t split_items = 0u;
+    // Render kernel, split items of at most eight pixels in the pipelined form: 1: the primary rays of a pixel are
+    // resolved against a list of the leaves the pixel's pyramid of camera rays touches, collected once per work item,
+    // instead of walking the tree.  Same image either way.
+    uint32_t pixel_lists = 0u;
+    // ... a pixel whose pyramid touches more leaves than this (at most PIXEL_LIST_MAX) gets no list
+    uint32_t pixel_list_len = PIXEL_LIST_MAX;
     // Persistent kernels: fewer resident workgroups per CU than the kernel allows (0: all of them; occupancy experiments).
     uint32_t blocks_per_cu = 0u;
     // Ray batches: 1 runs the plain one-lane-per-ray kernel instead of the streaming one (experiments).
     uint32_t intersect_static = 0u;
 };
 
-// d_counters: 7 x u64 in device memory {rays, node visits, primitive tests, wave-level node passes, primitive
-//             passes, shading passes, refill passes}; the kernels ADD to them.
+// d_counters: 32 x u64 in device memory, zero before the launch: [0..6] {rays, node visits, primitive tests, wave-level
+//             node passes, primitive passes, shading passes, refill passes}, [8..11] the work-queue heads (d_heads),
+//             [12..13] idle lane slots of node passes, [14] pixels that got a candidate leaf list; the kernels ADD to them.
 // d_heads:    8 x u32 work-queue heads, zero before the launch.
 // n_chunks (1 .. spp) sample chunks whose lengths differ by at most one (RenderGeom).
 // n_chunks > 1: the kernel writes n_chunks partial images (each width*height*3 floats) to d_partial and a second
@@ -61,7 +68,10 @@ struct RenderTuning {
 hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
                          float* d_accum, float* d_partial, uint32_t n_chunks, unsigned long long* d_counters,
                          unsigned int* d_heads, int cu_count, bool count_visits, const RenderTuning& tuning,
-                         hipStream_t stream);
+                         hipStream_t stream, uint32_t* d_lists = nullptr);
+// Whether a launch with these parameters resolves primary rays against per-pixel leaf lists; it then needs d_lists:
+// width * height * PIXEL_LIST_DWORDS dwords of device memory (written by a pass that launch_render runs first).
+bool render_takes_pixel_lists(const SceneDev& S, uint32_t width, uint32_t height, uint32_t n_chunks, const RenderTuning& tuning);
 // d_head: one u32, zero before the launch (the batch's ray counter).
 hipError_t launch_intersect(const SceneDev& S, const rrt_ray* d_rays, size_t n, float tmin, float tmax, rrt_hit* d_out,
                             unsigned long long* d_counters, unsigned int* d_head, int cu_count, bool count_visits,

@@ -235,6 +235,33 @@ __global__ void k_add(float* __restrict__ dst, const float* __restrict__ src, si
     }
 }
 
+// The candidate leaves of every pixel's primary rays (rrt_device.h: frustum_leaves), one lane per pixel, written to
+// `lists` (PIXEL_LIST_DWORDS dwords per pixel, row-major).  Neighbouring pixels' pyramids walk the same nodes, so the
+// lanes of a wavefront (an 8x8 block of pixels) stay together.
+// listed (one u64): the kernel adds the number of pixels that got a list.
+__global__ __launch_bounds__(256) void k_pixel_lists(SceneDev S, uint32_t width, uint32_t height, uint32_t max_len, uint32_t* __restrict__ lists,
+                                                     unsigned long long* __restrict__ listed) {
+    const uint32_t tiles_x = (width + 7u) / 8u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t x = (wave % tiles_x) * 8u + (lane & 7u), y = (wave / tiles_x) * 8u + (lane >> 3);
+    const bool inside = x < width && y < height;
+    uint32_t refs[PIXEL_LIST_MAX];
+    float entry[PIXEL_LIST_MAX];
+    uint32_t n = 0xFFFFFFFFu;
+    if (inside) n = frustum_leaves<(int)PIXEL_LIST_MAX>(S, pixel_frustum(S.cam, x, y, width, height), max_len, refs, entry);
+    const unsigned long long got = __ballot(inside && n != 0xFFFFFFFFu);
+    if (lane == 0u && got != 0ull) atomicAdd(listed, (unsigned long long)__popcll(got));
+    if (!inside) return;
+    uint32_t* dst = lists + (size_t)(y * width + x) * PIXEL_LIST_DWORDS;
+    dst[0] = n;
+    dst[1] = 0u;
+    for (uint32_t i = 0; i < PIXEL_LIST_MAX; ++i) {
+        const bool have = n != 0xFFFFFFFFu && i < n;
+        dst[2u + 2u * i] = have ? refs[i] : 0u;
+        dst[3u + 2u * i] = have ? __float_as_uint(entry[i]) : 0u;
+    }
+}
+
 // ---- launchers --------------------------------------------------------------------------------
 
 uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t samples_per_item) {
@@ -254,10 +281,16 @@ uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t s
     return (uint32_t)n;
 }
 
+bool render_takes_pixel_lists(const SceneDev& S, uint32_t width, uint32_t height, uint32_t n_chunks, const RenderTuning& tuning) {
+    if (tuning.pixel_lists == 0u || tuning.split_items == 0u || tuning.overlap_items == 0u || width >= 65536u || height >= 65536u) return false;
+    if (S.unroll_shift != 0u || S.has_instances != 0u || n_chunks < 64u / (uint32_t)LIST_PIXELS) return false;
+    return true;
+}
+
 hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uint32_t spp, uint32_t spp_offset,
                          float* d_accum, float* d_partial, uint32_t n_chunks, unsigned long long* d_counters,
                          unsigned int* d_heads, int cu_count, bool count_visits, const RenderTuning& tuning,
-                         hipStream_t stream) {
+                         hipStream_t stream, uint32_t* d_lists) {
     // the pipelined form packs a lane's pixel coordinates into 16 bits each
     const bool pipelined = tuning.overlap_items != 0u && width < 65536u && height < 65536u;
     // Scenes without instances, where the caller asks for it: an item is a few pixels times as many of their sample chunks as make 64 lanes -- all chunks of the
@@ -301,6 +334,7 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     G.n_groups = (n_chunks + sub - 1u) / sub;
     G.pix_log2 = pix_log2;
     G.tw_log2 = tw_log2;
+    G.lists = nullptr;
     G.n_work = G.n_tiles * G.n_groups;
     G.node_share_64ths = tuning.node_share_64ths;
     G.leave_walk = tuning.leave_walk;
@@ -312,6 +346,20 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     const unsigned variant = (scaled ? 16u : 0u) | ((unsigned)mode << 2) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
     if (mode == MODE_UNROLLED) {
         e = launch_render_unrolled(count_visits, pipelined, scaled, S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream);
+    } else if (pix_log2 != 6u && d_lists != nullptr && render_takes_pixel_lists(S, width, height, n_chunks, tuning) && (1u << pix_log2) <= (uint32_t)LIST_PIXELS) {
+        // split items of a few pixels, two items in flight: primary rays resolved against per-pixel leaf lists, which
+        // a pass over the frame's pixels collects first
+        const uint32_t waves = ((width + 7u) / 8u) * ((height + 7u) / 8u);
+        hipLaunchKernelGGL(k_pixel_lists, dim3((waves + 3u) / 4u), dim3(256), 0, stream, S, width, height,
+                           std::min(tuning.pixel_list_len, PIXEL_LIST_MAX), d_lists, d_counters + 14);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        G.lists = d_lists;
+        switch ((scaled ? 2u : 0u) | (count_visits ? 1u : 0u)) {
+            case 3u: e = launch_render_variant<MODE_FLAT, true, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 2u: e = launch_render_variant<MODE_FLAT, false, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 1u: e = launch_render_variant<MODE_FLAT, true, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            default: e = launch_render_variant<MODE_FLAT, false, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        }
     } else if (pix_log2 != 6u) {  // (scenes without instances: the items are split)
         switch ((scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {
             case 7u: e = launch_render_variant<MODE_FLAT, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;

@@ -186,7 +186,14 @@ struct RenderGeom {
     uint32_t n_groups;          // work items per tile (pipelined form: an item holds several consecutive chunks of its pixels)
     uint32_t pix_log2, tw_log2; // pipelined form: an item is 2^pix_log2 pixels (a tile 2^tw_log2 pixels wide) x 64 / pixels chunks
     uint32_t chunk_r;           // the first chunk_r chunks hold chunk_q + 1 samples, the others chunk_q
+    const uint32_t* lists;      // per-pixel candidate leaf lists (PIXEL_LIST_DWORDS dwords per pixel, row-major), or null
 };
+// A pixel's list of candidate leaves for its primary rays, as k_pixel_lists writes it: dword 0 = number of entries (or
+// 0xFFFFFFFF: no list, the pixel's primary rays walk the tree), dword 1 unused, then per entry the leaf reference and
+// the bit pattern of a lower bound of the ray parameter at which a ray of the pixel can reach the leaf's box, in
+// ascending order of that bound.
+static constexpr uint32_t PIXEL_LIST_MAX = 11u;
+static constexpr uint32_t PIXEL_LIST_DWORDS = 2u * (PIXEL_LIST_MAX + 1u);
 // First sample (relative to the launch's first) and length of chunk c of a launch cut as RenderGeom describes.
 RRT_HD static inline uint32_t chunk_first(uint32_t c, uint32_t q, uint32_t r) { return c * q + (c < r ? c : r); }
 RRT_HD static inline uint32_t chunk_len(uint32_t c, uint32_t q, uint32_t r) { return q + (c < r ? 1u : 0u); }

@@ -109,12 +109,21 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 // SPLIT (scenes without instances): an item's 64 lanes are 2^G.pix_log2 pixels times several of their
 // sample chunks instead of 64 pixels times one (launch_render picks the split); a template parameter because the
 // general index arithmetic costs the other scenes 1-3 % when it is merely switched off at run time.
-template <int MODE, bool COUNT, bool PIPELINED, bool SCALED, bool SPLIT = false>
+// LISTS (split items of at most LIST_PIXELS pixels, pipelined form, scenes without instances): a kernel run before this one
+// (k_pixel_lists) has collected, for every pixel, the leaves the pixel's pyramid of camera rays touches.  When a
+// wavefront draws an item it copies the lists of the item's pixels to LDS; a lane that starts a sample of a pixel with a
+// list resolves its primary ray against that list inside the shading phase -- a handful of primitive tests instead of a
+// walk -- and shades it in a second round of the same phase, so that the walk phase of a trip carries bounce rays
+// only and a sample costs one trip less.
+static constexpr int LIST_PIXELS = 8;   // pixels of an item that get a list
+template <int MODE, bool COUNT, bool PIPELINED, bool SCALED, bool SPLIT = false, bool LISTS = false>
 __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? RRT_UNROLLED_WAVES : RRT_FLAT_WAVES) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
     constexpr bool INST = MODE == MODE_TWO_LEVEL;
     static_assert(!(SCALED && INST), "the scaled slab arithmetic is for scenes walked on one grid");
+    static_assert(!LISTS || (SPLIT && PIPELINED && MODE == MODE_FLAT), "pixel lists: split items, pipelined form, no instances");
+    __shared__ __align__(16) uint32_t s_lists[LISTS ? (RENDER_BLOCK / WAVE) * RRT_ITEM_RING * LIST_PIXELS * PIXEL_LIST_DWORDS : 1];
     // RENDER_STACK entries per lane of the traversal stack live in LDS, the rest in private memory (six workgroups per
     // CU, seven in the pipelined form, whose large scenes gain more from the extra wavefront than they lose to its
     // spills).  Instanced scenes add six floats per lane for the world-space ray of a lane that walks inside a mesh.
@@ -352,6 +361,22 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 rec[0] = x0; rec[1] = y0; rec[2] = chunk; rec[3] = n_spp; rec[4] = first_sample; rec[5] = flip;
                 if constexpr (SPLIT) { rec[6] = n_valid; rec[7] = n_long; }
             }
+            if constexpr (LISTS) {
+                // the lists of the item's pixels, from the frame's list buffer to LDS: one 16-byte quarter-dozen per lane
+                // (the slot's old lists are free: nobody is on the item that held them)
+                constexpr uint32_t QUADS = PIXEL_LIST_DWORDS / 4u;
+                if (work != NO_WORK && lane < (QUADS << pix_log2)) {
+                    const uint32_t pix = lane / QUADS, quad = lane % QUADS;
+                    const uint32_t px_x = x0 + (pix & ((1u << tw_log2) - 1u)), px_y = y0 + (pix >> tw_log2);
+                    uint4 v = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // (a pixel outside the frame is never taken)
+                    if (px_x < width && px_y < height)
+                        v = reinterpret_cast<const uint4*>(G.lists + (size_t)(px_y * width + px_x) * PIXEL_LIST_DWORDS)[quad];
+                    uint32_t* dst = s_lists + (((threadIdx.x >> 6) * RING + slot) * (uint32_t)LIST_PIXELS + pix) * PIXEL_LIST_DWORDS + quad * 4u;
+                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             flip ^= (uint32_t)RRT_LANE_FLIP;
             return work != NO_WORK;
         };
@@ -365,6 +390,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
         uint32_t xy = 0;           // the lane's pixel, x | y << 16
         uint32_t next_sample = 0;  // absolute index of the next sample to start
         uint32_t left = 0;         // samples of the item not yet finished
+        [[maybe_unused]] uint32_t lst = 0;  // LISTS: where the list of the lane's pixel starts in s_lists
         bool has_ray = false;    // a ray is in flight (being walked, or waiting to be shaded)
         V3 sum = v3(0.f, 0.f, 0.f);
         V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f), beta = v3(0.f, 0.f, 0.f);
@@ -440,9 +466,14 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
             __builtin_amdgcn_s_setprio(RRT_SHADE_PRIO);
 #endif
             // ---- shade phase: every lane whose walk is complete shades its hit; a lane whose path ended starts its
-            // next sample, a lane whose item ended (or that has none yet) takes its pixel of the item it is due for
+            // next sample, a lane whose item ended (or that has none yet) takes its pixel of the item it is due for.
+            // LISTS: a lane that starts a sample of a pixel with a list resolves the primary ray against the list on
+            // the spot; those lanes are shaded in a second round of the phase (whose own new samples walk the tree).
+            for (int round = 0; round < (LISTS ? 2 : 1); ++round) {
             const bool shade_now = has_ray && T.cur == REF_DONE;
             bool take = stage < RING;  // on an item without having taken its pixel of it
+            [[maybe_unused]] bool listed = false;  // the lane's new ray is resolved against its pixel's list
+            if (LISTS && round == 1 && __ballot(shade_now) == 0ull) break;
             if (shade_now || take) {
                 bool alive = false;
                 V3 radiance = v3(0.f, 0.f, 0.f);  // what the path emits: one term, at its last surface (see above)
@@ -500,6 +531,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                             left = n_spp;
                             next_sample = SPLIT ? first_sample : rec[4];
                             sum = v3(0.f, 0.f, 0.f);
+                            if constexpr (LISTS)
+                                lst = (((threadIdx.x >> 6) * RING + slot_of(stage)) * (uint32_t)LIST_PIXELS + (pl & ((1u << pix_log2) - 1u))) * PIXEL_LIST_DWORDS;
                             stage += 4u;
                             start = true;
                         } else {
@@ -517,9 +550,29 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         beta = v3(1.f, 1.f, 1.f);
                         depth = S.max_depth;
                         has_ray = true;
+                        if constexpr (LISTS) listed = round == 0 && s_lists[lst] != 0xFFFFFFFFu;
                     }
                 }
-                if (has_ray) trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                if (has_ray && !(LISTS && listed)) trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+            }
+            if constexpr (LISTS) {
+                if (round == 1 || __ballot(listed) == 0ull) break;
+                // the primary rays of the lanes that just started a sample of a listed pixel: closest hit over the
+                // primitives of the pixel's candidate leaves
+                if (listed) {
+                    T.best.t = __builtin_inff(); T.best.u = 0.f; T.best.v = 0.f; T.best.what = WHAT_NONE; T.best.inst = -1;
+                    T.cur = REF_DONE;
+                    const lds_u32* list = (const lds_u32*)s_lists + lst;
+                    const uint32_t n_listed = list[0];
+                    if (COUNT && first_active_lane()) cnt.wave_prims++;
+                    for (uint32_t i = 0; i < n_listed; ++i) {
+                        // (leaves in ascending order of the earliest ray parameter at which the pixel's rays can reach
+                        // them: nothing behind the hit already found needs a test)
+                        if (__uint_as_float(list[3u + 2u * i]) > T.best.t) break;
+                        test_listed_leaf<COUNT>(S, list[2u + 2u * i], o, d, S.t_min, T.best, cnt);
+                    }
+                }
+            }
             }
         }
     }
@@ -556,19 +609,19 @@ static hipError_t resident_blocks_per_cu(Kernel kernel, std::atomic<int>& cache,
 }
 
 // max_blocks_per_cu: 0, or fewer resident workgroups per CU than the kernel allows (RenderTuning::blocks_per_cu).
-template <int MODE, bool COUNT, bool PIPELINED, bool SCALED = false, bool SPLIT = false>
+template <int MODE, bool COUNT, bool PIPELINED, bool SCALED = false, bool SPLIT = false, bool LISTS = false>
 static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, float* out, unsigned long long* d_counters,
                                         unsigned int* d_heads, int cu_count, uint32_t max_blocks_per_cu, hipStream_t stream) {
     // persistent grid: as many workgroups as the chip holds at once (never more than there are work items)
     static std::atomic<int> cache{0};
     int blocks_per_cu = 1;
-    if (hipError_t e = resident_blocks_per_cu(k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT>, cache, blocks_per_cu); e != hipSuccess) return e;
+    if (hipError_t e = resident_blocks_per_cu(k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT, LISTS>, cache, blocks_per_cu); e != hipSuccess) return e;
     if (max_blocks_per_cu != 0u && (int)max_blocks_per_cu < blocks_per_cu) blocks_per_cu = (int)max_blocks_per_cu;
     unsigned long long blocks = (unsigned long long)blocks_per_cu * (unsigned)cu_count;
     const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;
     if (blocks > needed) blocks = needed;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
+    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT, LISTS>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
     return hipGetLastError();
 }
 

@@ -241,6 +241,90 @@ def test_image_does_not_depend_on_how_items_are_cut(rrt, name):
     r.close()
 
 
+LIST_FRAMES = ((97, 55, 16, 8, 0), (97, 55, 24, 16, 5), (61, 47, 32, 32, 0), (64, 33, 100, 8, 0), (37, 21, 100, 32, 7),
+               (9, 7, 64, 32, 0), (1, 1, 50, 16, 0), (130, 70, 9, 9, 2))
+
+
+@pytest.mark.parametrize("name", ["default", "suzanne", "mixed", "synthetic"])
+def test_image_does_not_depend_on_pixel_lists(rrt, oracle, name):
+    """Scenes without instances, items of at most 8 pixels, two items in flight: a pass over the frame's pixels first
+    collects, per pixel, the leaves whose boxes the pyramid of the pixel's camera rays touches (rrt_tuning.pixel_lists;
+    at most pixel_list_len of them, else the pixel keeps walking the tree), and the pixel's primary rays test those
+    leaves in order of entry distance instead of walking.  The list is a superset of the leaves any of the pixel's
+    primary rays can enter and the primitive tests decide, so ray counts and images are identical bit for bit with and
+    without lists and with lists of any length: on frames whose edges cut items of every shape, with chunks of unequal
+    length, a sample offset, both forms of the box arithmetic, and with the counting variant of the kernel -- whose node
+    visits must go down, since listed primary rays visit none.  Then the same seed against the oracle."""
+    scene = helpers.SCENES[name](rrt)
+    r, rc = rrt.Renderer(seed=21), rrt.Renderer(seed=21, count_visits=True)
+    r.upload(scene)
+    rc.upload(scene)
+    listed_somewhere = False
+    for width, height, spp, chunks, offset in LIST_FRAMES:
+        r.set_tuning(overlap_items=1, split_items=1, chunks=chunks, pixel_lists=0)
+        plain, s0 = r.render(width, height, spp, spp_offset=offset)
+        for length, scaled in ((None, 1), (1, 1), (3, 0), (6, 1)):
+            r.set_tuning(pixel_lists=1, pixel_list_len=length, scaled_slab=scaled)
+            img, s1 = r.render(width, height, spp, spp_offset=offset)
+            assert s1.chunks == chunks and s0.rays == s1.rays and np.array_equal(plain, img), (name, width, height, spp, chunks, length)
+            if length is None:
+                listed_somewhere |= r.info().pixel_list_permille > 0
+        r.set_tuning(scaled_slab=None)
+    assert listed_somewhere
+    w, h, spp = 96, 54, 16
+    rc.set_tuning(overlap_items=1, split_items=1, chunks=8, pixel_lists=0)
+    walked, c0 = rc.render(w, h, spp)
+    rc.set_tuning(pixel_lists=1)
+    listed, c1 = rc.render(w, h, spp)
+    assert c0.rays == c1.rays and np.array_equal(walked, listed)
+    assert rc.info().pixel_list_permille > 0 and c1.node_visits < c0.node_visits
+    r.set_tuning(chunks=8, pixel_lists=1, pixel_list_len=None)
+    img, st = r.render(w, h, spp)
+    assert np.array_equal(img, listed)
+    ref, ref_rays = oracle.OracleScene(scene).render(w, h, spp, seed=21)
+    assert abs(int(st.rays) - ref_rays) <= max(2, ref_rays // 1000)
+    assert_same_seed_images_agree(img, ref, min_close=0.995, what=name)
+    r.close()
+    rc.close()
+
+
+def test_pixel_lists_with_hostile_cameras(rrt):
+    """Per-pixel leaf lists where the pyramid of a pixel's rays is awkward: a camera inside the geometry (boxes that
+    contain the apex), a field of view of 170 degrees (pyramid faces almost in one plane) and of 0.2 degrees (almost
+    parallel faces), geometry far from the origin and tiny, flat geometry seen edge-on, a camera matrix scaled by 1e-3
+    and 1e3, and a frame one pixel wide.  Same rays and images as without lists, bit for bit."""
+    g = np.random.default_rng(5)
+    cases = [(1.0, 0.0, 40.0, 3.0, 1.0, None), (1.0, 0.0, 60.0, 0.0, 1.0, None), (1.0, 0.0, 170.0, 1.5, 1.0, None),
+             (1.0, 0.0, 0.2, 40.0, 1.0, None), (1e-3, 2e3, 40.0, 3.0, 1.0, None), (1e3, -5e4, 40.0, 3.0, 1.0, None),
+             (1.0, 0.0, 40.0, 3.0, 1e-3, None), (1.0, 0.0, 40.0, 3.0, 1e3, None), (1.0, 0.0, 40.0, 3.0, 1.0, 1),
+             (1.0, 0.0, 40.0, 3.0, 1.0, 2)]
+    for scale, offset, fov, back, cam_len, flat_axis in cases:
+        n = 3000
+        centres = g.uniform(-1, 1, (n, 1, 3)) * scale
+        tris = centres + g.normal(0, 0.04 * scale, (n, 3, 3))
+        if flat_axis is not None:
+            tris[..., flat_axis] = 0.0
+        tris = (tris + offset).astype(np.float32)
+        s = rrt.Scene()
+        m = s.add_material(rrt.Lambertian(0.7, 0.6, 0.5))
+        glass = s.add_material(rrt.Dielectric(1.5))
+        s.add_triangles(tris[: n // 2], m)
+        s.add_triangles(tris[n // 2:], glass)
+        s.add_sphere((offset + 0.3 * scale, offset, offset), 0.2 * scale, m)
+        s.background = (0.6, 0.7, 0.9)
+        c2w = np.float32([[cam_len, 0, 0, offset], [0, cam_len, 0, offset], [0, 0, cam_len, offset + back * scale]])
+        s.camera = rrt.Camera(1.5, fov, c2w)
+        r = rrt.Renderer(seed=3)
+        r.upload(s)
+        for w, h, spp, chunks in ((72, 48, 16, 8), (1, 40, 32, 32), (50, 1, 16, 16)):
+            r.set_tuning(overlap_items=1, split_items=1, chunks=chunks, pixel_lists=0)
+            plain, s0 = r.render(w, h, spp)
+            r.set_tuning(pixel_lists=1)
+            img, s1 = r.render(w, h, spp)
+            assert s0.rays == s1.rays and np.array_equal(plain, img), (scale, offset, fov, back, cam_len, flat_axis, w, h)
+        r.close()
+
+
 def test_scaled_box_test_with_hostile_coordinates(rrt, oracle):
     """The scaled form of the box test on triangle soups far from the origin, tiny or huge, flat in one axis, seen from
     outside and from inside along an axis; and cameras whose ray directions are too long or too short for it, for which
@@ -426,7 +510,8 @@ def test_headline_workload_at_full_size(rrt):
 
 def test_headline_kernel_variant_at_full_size(rrt, oracle):
     """The instantiation of the render kernel the benchmark times -- scene without instances, two items in flight,
-    scaled box arithmetic, items of a few pixels x many sample chunks -- on the benchmark's own scene and frame
+    scaled box arithmetic, items of a few pixels x many sample chunks, per-pixel leaf lists for the primary rays -- on
+    the benchmark's own scene and frame
     (1,048,576 triangles, 3840x2160: thirty bands of one-pixel-wide tiles, millions of work items through the eight
     queues, up to 32 partial images), against the whole-tile form of the same kernel: identical images and ray
     counts.  It replaces the reference's per-pixel loop (src/main.rs:87-103), and every pixel's sum must be the
@@ -447,6 +532,8 @@ def test_headline_kernel_variant_at_full_size(rrt, oracle):
         r.render_device(w, h, spp, off, a.ptr, 0)
         sa = r.render_stats()
         assert sa.chunks == want_chunks, (spp, sa.chunks)
+        if spp >= 100:  # (the library's rule: from a few dozen samples of listed pixels on)
+            assert r.info().pixel_list_permille > 500  # primary rays resolved against per-pixel leaf lists
         r.set_tuning(chunks=sa.chunks, split_items=0)  # the same chunks as items of 64 pixels x one chunk
         r.render_device(w, h, spp, off, b.ptr, 0)
         sb = r.render_stats()

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--tune", default="")
     ap.add_argument("--count", action="store_true", help="counting variant of the kernel: lane utilisation per pass")
     ap.add_argument("--device-build", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare every tuning set's image and ray count with the first set's (bit for bit)")
     args = ap.parse_args()
     import numpy as np
     import rrt_pkg
@@ -33,8 +34,9 @@ def main():
     buf = helpers.DeviceArray((h, w, 3))
     sets = [t for t in args.tune.split(";")] if args.tune else [""]
     for spp in [int(x) for x in args.spp.split(",")]:
+        first_img, first_rays = None, None
         for t in sets:
-            knobs = {k: None for k in ("chunks", "split_items", "node_share_64ths", "leave_walk", "leave_ready", "overlap_items", "band_tiles", "scaled_slab", "blocks_per_cu")}
+            knobs = {k: None for k in ("chunks", "split_items", "node_share_64ths", "leave_walk", "leave_ready", "overlap_items", "band_tiles", "scaled_slab", "blocks_per_cu", "pixel_lists", "pixel_list_len")}
             for kv in filter(None, t.split(",")):
                 k, v = kv.split("=")
                 knobs[k] = int(v)
@@ -50,6 +52,13 @@ def main():
                 extra = (f"  util n/p/s {st.node_visits / max(64 * st.node_wave_steps, 1):.3f}/{st.prim_tests / max(64 * st.prim_wave_steps, 1):.3f}/"
                          f"{st.rays / max(64 * st.shade_wave_passes, 1):.3f}  nodes/prims per ray {st.node_visits / st.rays:.2f}/{st.prim_tests / st.rays:.2f}"
                          f"  wave steps per 64 rays n/p/s {64 * st.node_wave_steps / st.rays:.1f}/{64 * st.prim_wave_steps / st.rays:.1f}/{64 * st.shade_wave_passes / st.rays:.2f}")
+            if args.check:
+                img = buf.numpy()
+                if first_img is None:
+                    first_img, first_rays = img, st.rays
+                else:
+                    same = np.array_equal(img, first_img)
+                    extra += f"  image {'identical' if same else 'DIFFERS in %d floats' % int((img != first_img).sum())}, rays {'equal' if st.rays == first_rays else 'DIFFER %d vs %d' % (st.rays, first_rays)}"
             print(f"cfg {args.config} spp {spp:5d} [{t or 'default':40s}] chunks {st.chunks:3d}  min {min(ms):9.2f} ms  med {float(np.median(ms)):9.2f} ms  {st.rays / min(ms) / 1e6:7.3f} Grays/s{extra}", flush=True)
     buf.free()
     r.close()
