@@ -577,6 +577,14 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // pixels of unequal cost to even out: suzanne 1080p x 256 spp 11.1 -> 10.6 ms, x 1024 spp 32.7 -> 29.9 ms; not on
     // scenes of a few primitives (12-primitive scene 0.94 -> 1.03 ms with it).
     bool split_items = tn.split_items != RRT_TUNE_AUTO ? tn.split_items != 0u : (!huge_scene && c->info.node_count >= 64u);
+    // Frames whose primary rays can take per-pixel candidate lists (below; whether a launch collects them also depends on
+    // what the last one found, which must not change how a frame is cut): a listed sample costs one trip less, so an
+    // item holds 16 samples per lane for its 16 trips (measured on MI355X, 1M-triangle scene at 4K with lists: 128 spp in
+    // 8 / 16 / 32 chunks 118.7 / 120.3 / 132.5 ms, 256 spp 223.2 / 220.1 / 231.3 ms, 100 spp 95.6 / 99.3 / 112.7 ms).
+    const bool pipelined_form = tn.overlap_items != RRT_TUNE_AUTO ? tn.overlap_items != 0u : big_scene;
+    const bool lists_possible = tn.pixel_lists != 0u && spp >= 32u && split_items && pipelined_form && !huge_scene &&
+                                c->sdev.unroll_shift == 0u && c->sdev.has_instances == 0u;
+    if (lists_possible && big_scene) per_item = 16u;
     uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? per_item : 16u);
     if (tn.chunks != RRT_TUNE_AUTO) n_chunks = std::min(tn.chunks, spp);
     while (n_chunks > 1u && (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * n_chunks > 0x7FFFFFFFull) n_chunks /= 2u;
@@ -664,7 +672,7 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // them costs about what one sample per pixel costs, and a listed pixel's samples then cost about a fifth less, so
     // they pay from a few dozen samples of listed pixels on.  The share of pixels that get a list (fine geometry: few) is
     // taken from the scene's last render whose statistics were read; until one was, every pixel is assumed to.
-    tuning.pixel_lists = tn.pixel_lists != RRT_TUNE_AUTO ? tn.pixel_lists : ((float)spp * c->list_share >= 32.0f ? 1u : 0u);
+    tuning.pixel_lists = tn.pixel_lists != RRT_TUNE_AUTO ? tn.pixel_lists : (lists_possible && (float)spp * c->list_share >= 32.0f ? 1u : 0u);
     if (tn.pixel_list_len != RRT_TUNE_AUTO) tuning.pixel_list_len = tn.pixel_list_len;
     // per-pixel candidate leaf lists for the primary rays (launch_render): a frame-sized buffer of the context, grown on
     // demand; the entry point that may not allocate goes without them

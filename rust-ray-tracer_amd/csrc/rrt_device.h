@@ -30,6 +30,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 __device__ __forceinline__ float length_squared(V3 a) { return dot(a, a); }
+__device__ __forceinline__ float norm1(V3 a) { return (fabsf(a.x) + fabsf(a.y)) + fabsf(a.z); }
 __device__ __forceinline__ V3 normalize(V3 a);  // defined after sqrt_rn
 __device__ __forceinline__ float comp(V3 a, uint32_t axis) { return axis == 0 ? a.x : (axis == 1 ? a.y : a.z); }
 #define RRT_PI 3.14159274101257324f  // std::f32::consts::PI
@@ -857,8 +858,10 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, float x, float 
 struct PixelFrustum {
     V3 o;
     V3 n[4];        // inward normals of the four side planes through o
+    V3 d[4];        // the rays through the four corners
     V3 a;           // the ray through the pixel's centre
     float inv_amax; // 1 / the largest a . d over the pyramid's rays d (attained at a corner: a . d is affine over the pixel)
+    float d_l1;     // the largest 1-norm of a corner ray
 };
 __device__ __forceinline__ PixelFrustum pixel_frustum(const CameraRec& cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
     // the jittered coordinates of the pixel lie in [px, px + 1] x [py, py + 1]; 1/64 of a pixel of slack on every side
@@ -880,7 +883,32 @@ __device__ __forceinline__ PixelFrustum pixel_frustum(const CameraRec& cam, uint
     for (int k = 0; k < 4; ++k)
         if (dot(F.n[k], F.a) < 0.0f) F.n[k] = -F.n[k];
     F.inv_amax = 1.0f / fmaxf(fmaxf(dot(F.a, d00), dot(F.a, d10)), fmaxf(dot(F.a, d11), dot(F.a, d01)));
+    F.d[0] = d00; F.d[1] = d10; F.d[2] = d11; F.d[3] = d01;
+    F.d_l1 = fmaxf(fmaxf(norm1(d00), norm1(d10)), fmaxf(norm1(d11), norm1(d01)));
     return F;
+}
+// False only if no ray of the pyramid can pass test_triangle for the triangle (v0, v0 + e1, v0 + e2):
+//   * every ray sees its back: test_triangle wants det = e1 . (d x e2) = d . (e2 x e1) above 1e-5, det is linear in d
+//     and every ray of the pixel is a convex combination of the corner rays, so det <= its largest corner value; or
+//   * its three corners lie outside one side plane, by more than rho: the triangle is the convex hull of its corners,
+//     so it then lies outside the pyramid by that much.  rho covers what test_triangle's own rounding can add to a
+//     triangle's extent: its barycentric coordinates carry an error of a few ulps of |o - v0| / |e|, i.e. it accepts
+//     rays that pass the triangle at a few ulps of the distance to it.
+// Both with allowances of tens of ulps of the sums' terms.
+__device__ __forceinline__ bool frustum_touches_triangle(const PixelFrustum& F, V3 v0, V3 e1, V3 e2) {
+    const V3 m = cross(e2, e1);
+    const float det_max = fmaxf(fmaxf(dot(F.d[0], m), dot(F.d[1], m)), fmaxf(dot(F.d[2], m), dot(F.d[3], m)));
+    const float le1 = norm1(e1), le2 = norm1(e2);
+    if (det_max < -4e-6f * (le1 * le2 * F.d_l1)) return false;
+    const V3 p0 = v0 - F.o, p1 = p0 + e1, p2 = p0 + e2;
+    const float rho = 4e-6f * ((norm1(p0) + le1) + le2);
+    bool in = true;
+    for (int k = 0; k < 4; ++k) {
+        const V3 n = F.n[k];
+        const float far_in = fmaxf(fmaxf(dot(n, p0), dot(n, p1)), dot(n, p2));
+        in = in && (far_in >= -rho * norm1(n));
+    }
+    return in;
 }
 // False only if the box [mn, mx] lies outside one of the pyramid's side planes (conservative: the plane test is made
 // at the box's corner furthest inside, with a relative allowance for the rounding of the sum).
@@ -904,10 +932,12 @@ __device__ __forceinline__ float frustum_box_entry(const PixelFrustum& F, V3 mn,
     const float lo = ((x + y) + z) - 4e-6f * ((fabsf(x) + fabsf(y)) + fabsf(z));
     return fmaxf(lo * F.inv_amax, 0.0f) * 0.9999f;
 }
-// Collects the leaves of the scene's (one) BVH whose stored boxes the pyramid touches, ordered by the lower bound of
-// the ray parameter at which a ray of the pixel can reach them: refs[i], entry[i] for i < the returned count, or
-// 0xFFFFFFFF when there are more than `max_len` (<= KMAX; the pixel's primary rays then walk the tree like every other
-// ray).  A plain depth-first walk on a private stack.
+// Collects the primitives a primary ray of the pixel can hit, as leaf references (a triangle as a triangle leaf of
+// one): the spheres and rectangles of the leaves of the scene's (one) BVH whose stored boxes the pyramid touches, and
+// those of their triangles that frustum_touches_triangle keeps; ordered by the lower bound of the ray parameter at
+// which a ray of the pixel can reach their leaf's box: refs[i], entry[i] for i < the returned count, or 0xFFFFFFFF
+// when there are more than `max_len` (<= KMAX; the pixel's primary rays then walk the tree like every other ray).
+// A plain depth-first walk on a private stack.
 template <int KMAX>
 __device__ __forceinline__ uint32_t frustum_leaves(const SceneDev& S, const PixelFrustum& F, uint32_t max_len, uint32_t* refs, float* entry) {
     int todo[STACK_DEPTH];
@@ -941,13 +971,25 @@ __device__ __forceinline__ uint32_t frustum_leaves(const SceneDev& S, const Pixe
             }
         } else {
             const uint32_t kind = ((uint32_t)cur >> 28) & 7u;
-            if (kind <= KIND_RECT) {  // triangles, a sphere, a rectangle (an empty child slot is skipped)
-                if (n == max_len) return 0xFFFFFFFFu;  // one more than a list may hold: no list, no point in going on
-                // insertion by entry bound (lists are a handful of entries long)
+            // insertion by entry bound (lists are a handful of entries long)
+            auto insert = [&](uint32_t ref) {
                 uint32_t k = n;
                 while (k > 0u && entry[k - 1u] > cur_t) { refs[k] = refs[k - 1u]; entry[k] = entry[k - 1u]; --k; }
-                refs[k] = (uint32_t)cur; entry[k] = cur_t;
+                refs[k] = ref; entry[k] = cur_t;
                 n++;
+            };
+            if (kind == KIND_TRI) {
+                const uint32_t count = (((uint32_t)cur >> 25) & 7u) + 1u, first = (uint32_t)cur & REF_OFFSET_MASK;
+                for (uint32_t j = 0; j < count; ++j) {
+                    const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tris) + (size_t)(first + j) * 48u);
+                    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                    if (!frustum_touches_triangle(F, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z))) continue;
+                    if (n == max_len) return 0xFFFFFFFFu;  // one more than a list may hold: no list, no point in going on
+                    insert((KIND_TRI << 28) | (first + j));
+                }
+            } else if (kind <= KIND_RECT) {  // a sphere, a rectangle (an empty child slot is skipped)
+                if (n == max_len) return 0xFFFFFFFFu;
+                insert((uint32_t)cur);
             }
         }
         if (sp == 0) break;

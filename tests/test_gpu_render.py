@@ -527,7 +527,7 @@ def test_headline_kernel_variant_at_full_size(rrt, oracle):
     assert info.tri_count == 1048576 and info.scaled_slab == 1 and info.unrolled_instances == 0
     w, h = 3840, 2160
     a, b = helpers.DeviceArray((h, w, 3)), helpers.DeviceArray((h, w, 3))
-    for spp, off, chunks, want_chunks in ((32, 0, 16, 16), (256, 0, 32, 32), (100, 0, None, 8), (128, 0, None, 16), (128, 128, None, 16), (128, 896, None, 16)):
+    for spp, off, chunks, want_chunks in ((32, 0, 16, 16), (256, 0, 32, 32), (100, 0, None, 8), (128, 0, None, 8), (128, 128, None, 8), (128, 896, None, 8)):
         r.set_tuning(chunks=chunks, split_items=None)  # the library's rule: split items on this scene
         r.render_device(w, h, spp, off, a.ptr, 0)
         sa = r.render_stats()

@@ -59,6 +59,7 @@ def main():
                 else:
                     same = np.array_equal(img, first_img)
                     extra += f"  image {'identical' if same else 'DIFFERS in %d floats' % int((img != first_img).sum())}, rays {'equal' if st.rays == first_rays else 'DIFFER %d vs %d' % (st.rays, first_rays)}"
+            extra += f"  listed {r.info().pixel_list_permille / 10:.1f}%"
             print(f"cfg {args.config} spp {spp:5d} [{t or 'default':40s}] chunks {st.chunks:3d}  min {min(ms):9.2f} ms  med {float(np.median(ms)):9.2f} ms  {st.rays / min(ms) / 1e6:7.3f} Grays/s{extra}", flush=True)
     buf.free()
     r.close()
