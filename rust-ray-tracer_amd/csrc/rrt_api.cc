@@ -581,8 +581,7 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // what the last one found, which must not change how a frame is cut): a listed sample costs one trip less, so an
     // item holds 16 samples per lane for its 16 trips (measured on MI355X, 1M-triangle scene at 4K with lists: 128 spp in
     // 8 / 16 / 32 chunks 118.7 / 120.3 / 132.5 ms, 256 spp 223.2 / 220.1 / 231.3 ms, 100 spp 95.6 / 99.3 / 112.7 ms).
-    const bool pipelined_form = tn.overlap_items != RRT_TUNE_AUTO ? tn.overlap_items != 0u : big_scene;
-    const bool lists_possible = tn.pixel_lists != 0u && spp >= 32u && split_items && pipelined_form && !huge_scene &&
+    const bool lists_possible = tn.pixel_lists != 0u && spp >= 32u && split_items && !huge_scene &&
                                 c->sdev.unroll_shift == 0u && c->sdev.has_instances == 0u;
     if (lists_possible && big_scene) per_item = 16u;
     uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? per_item : 16u);

@@ -282,7 +282,7 @@ uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t s
 }
 
 bool render_takes_pixel_lists(const SceneDev& S, uint32_t width, uint32_t height, uint32_t n_chunks, const RenderTuning& tuning) {
-    if (tuning.pixel_lists == 0u || tuning.split_items == 0u || tuning.overlap_items == 0u || width >= 65536u || height >= 65536u) return false;
+    if (tuning.pixel_lists == 0u || tuning.split_items == 0u || width >= 65536u || height >= 65536u) return false;
     if (S.unroll_shift != 0u || S.has_instances != 0u || n_chunks < 64u / (uint32_t)LIST_PIXELS) return false;
     return true;
 }
@@ -347,18 +347,22 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     if (mode == MODE_UNROLLED) {
         e = launch_render_unrolled(count_visits, pipelined, scaled, S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream);
     } else if (pix_log2 != 6u && d_lists != nullptr && render_takes_pixel_lists(S, width, height, n_chunks, tuning) && (1u << pix_log2) <= (uint32_t)LIST_PIXELS) {
-        // split items of a few pixels, two items in flight: primary rays resolved against per-pixel leaf lists, which
-        // a pass over the frame's pixels collects first
+        // split items of a few pixels: primary rays resolved against per-pixel candidate lists, which a pass over the
+        // frame's pixels collects first
         const uint32_t waves = ((width + 7u) / 8u) * ((height + 7u) / 8u);
         hipLaunchKernelGGL(k_pixel_lists, dim3((waves + 3u) / 4u), dim3(256), 0, stream, S, width, height,
                            std::min(tuning.pixel_list_len, PIXEL_LIST_MAX), d_lists, d_counters + 14);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         G.lists = d_lists;
-        switch ((scaled ? 2u : 0u) | (count_visits ? 1u : 0u)) {
-            case 3u: e = launch_render_variant<MODE_FLAT, true, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
-            case 2u: e = launch_render_variant<MODE_FLAT, false, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
-            case 1u: e = launch_render_variant<MODE_FLAT, true, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
-            default: e = launch_render_variant<MODE_FLAT, false, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+        switch ((scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {
+            case 7u: e = launch_render_variant<MODE_FLAT, true, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 6u: e = launch_render_variant<MODE_FLAT, true, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 5u: e = launch_render_variant<MODE_FLAT, false, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 4u: e = launch_render_variant<MODE_FLAT, false, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 3u: e = launch_render_variant<MODE_FLAT, true, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 2u: e = launch_render_variant<MODE_FLAT, true, false, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 1u: e = launch_render_variant<MODE_FLAT, false, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            default: e = launch_render_variant<MODE_FLAT, false, false, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
         }
     } else if (pix_log2 != 6u) {  // (scenes without instances: the items are split)
         switch ((scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {

@@ -101,6 +101,9 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_FLAT_WAVES
 #define RRT_FLAT_WAVES 7  // workgroups per CU the pipelined form is compiled for on scenes without instances
 #endif
+#ifndef RRT_ONE_LIST_ROUNDS
+#define RRT_ONE_LIST_ROUNDS 2  // one-item form with pixel lists: rounds of a shade phase (the new samples of all but the last take their lists)
+#endif
 #ifndef RRT_ONE_ITEM_WAVES
 #define RRT_ONE_ITEM_WAVES 6  // workgroups per CU the one-item form (small scenes) is compiled for
 #endif
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                                                          unsigned int* __restrict__ heads) {
     constexpr bool INST = MODE == MODE_TWO_LEVEL;
     static_assert(!(SCALED && INST), "the scaled slab arithmetic is for scenes walked on one grid");
-    static_assert(!LISTS || (SPLIT && PIPELINED && MODE == MODE_FLAT), "pixel lists: split items, pipelined form, no instances");
-    __shared__ __align__(16) uint32_t s_lists[LISTS ? (RENDER_BLOCK / WAVE) * RRT_ITEM_RING * LIST_PIXELS * PIXEL_LIST_DWORDS : 1];
+    static_assert(!LISTS || (SPLIT && MODE == MODE_FLAT), "pixel lists: split items, no instances");
+    __shared__ __align__(16) uint32_t s_lists[LISTS ? (RENDER_BLOCK / WAVE) * (PIPELINED ? RRT_ITEM_RING : 1) * LIST_PIXELS * PIXEL_LIST_DWORDS : 1];
     // RENDER_STACK entries per lane of the traversal stack live in LDS, the rest in private memory (six workgroups per
     // CU, seven in the pipelined form, whose large scenes gain more from the extra wavefront than they lose to its
     // spills).  Instanced scenes add six floats per lane for the world-space ray of a lane that walks inside a mesh.
@@ -177,6 +180,35 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
         return work;
     };
 
+    // LISTS: the wavefront copies the lists of an item's pixels (tile at (x0, y0), 2^pix_log2 pixels in rows of 2^tw_log2)
+    // from the frame's list buffer to slot `slot` of its part of s_lists: one 16-byte piece per lane.
+    [[maybe_unused]] auto stage_lists = [&](uint32_t slot, uint32_t slots, uint32_t x0, uint32_t y0, uint32_t pix_log2, uint32_t tw_log2) {
+        constexpr uint32_t QUADS = PIXEL_LIST_DWORDS / 4u;
+        if (lane < (QUADS << pix_log2)) {
+            const uint32_t pix = lane / QUADS, quad = lane % QUADS;
+            const uint32_t px_x = x0 + (pix & ((1u << tw_log2) - 1u)), px_y = y0 + (pix >> tw_log2);
+            uint4 v = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // (a pixel outside the frame is never taken)
+            if (px_x < width && px_y < height)
+                v = reinterpret_cast<const uint4*>(G.lists + (size_t)(px_y * width + px_x) * PIXEL_LIST_DWORDS)[quad];
+            uint32_t* dst = s_lists + (((threadIdx.x >> 6) * slots + slot) * (uint32_t)LIST_PIXELS + pix) * PIXEL_LIST_DWORDS + quad * 4u;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    };
+    // LISTS: the closest hit of a primary ray over the primitives of its pixel's list (at dword `lst` of s_lists), in
+    // ascending order of the earliest ray parameter at which the pixel's rays can reach them: nothing behind the hit
+    // already found needs a test.  Leaves the lane as a completed walk does.
+    [[maybe_unused]] auto resolve_listed = [&](uint32_t lst, V3 o, V3 d, Trav& T) {
+        T.best.t = __builtin_inff(); T.best.u = 0.f; T.best.v = 0.f; T.best.what = WHAT_NONE; T.best.inst = -1;
+        T.cur = REF_DONE;
+        const lds_u32* list = (const lds_u32*)s_lists + lst;
+        const uint32_t n_listed = list[0];
+        if (COUNT && first_active_lane()) cnt.wave_prims++;
+        for (uint32_t i = 0; i < n_listed; ++i) {
+            if (__uint_as_float(list[3u + 2u * i]) > T.best.t) break;
+            test_listed_leaf<COUNT>(S, list[2u + 2u * i], o, d, S.t_min, T.best, cnt);
+        }
+    };
+
     if (!PIPELINED) {
         // One item at a time: the lanes start an item together and wait for its last path.  The form for
         // scenes whose trips are short (a handful of node steps, mostly first-ray misses), where the
@@ -220,6 +252,17 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
             Trav T;
             T.cur = REF_DONE;
             T.top = stack;
+            [[maybe_unused]] uint32_t lst = 0u;      // LISTS: where the list of the lane's pixel starts in s_lists
+            [[maybe_unused]] bool has_list = false;  // ... and whether the pixel has one
+            if constexpr (LISTS) {
+                // (the lists of the last item are free: every lane of the wavefront is through with it)
+                __builtin_amdgcn_wave_barrier();
+                stage_lists(0u, 1u, tx << G.tw_log2, ty << (G.pix_log2 - G.tw_log2), G.pix_log2, G.tw_log2);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                lst = ((threadIdx.x >> 6) * (uint32_t)LIST_PIXELS + (lane & ((1u << G.pix_log2) - 1u))) * PIXEL_LIST_DWORDS;
+                has_list = inside && s_lists[lst] != 0xFFFFFFFFu;
+            }
             if (has_ray) {
                 rng = rng_init(S.seed, pixel, spp_offset + s);
                 const float u = (float)x + rng_f32(rng);  // main.rs:92-93
@@ -228,7 +271,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 camera_ray(S.cam, u, v, width, height, o, d);
                 beta = v3(1.f, 1.f, 1.f);
                 depth = S.max_depth;
-                trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                if (LISTS && has_list) resolve_listed(lst, o, d, T);
+                else trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
             }
 
             for (;;) {
@@ -264,7 +308,12 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                     }
                     if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
                 }
-                // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray
+                // ---- shade phase: every lane whose walk is complete shades its hit and starts its next ray.
+                // LISTS: a lane that starts a sample of a pixel with a list resolves the primary ray against the list on
+                // the spot and is shaded in the phase's next round; the new samples of the last round walk the tree.
+                for (int round = 0; round < (LISTS ? RRT_ONE_LIST_ROUNDS : 1); ++round) {
+                [[maybe_unused]] bool listed = false;
+                if (LISTS && round != 0 && __ballot(has_ray && T.cur == REF_DONE) == 0ull) break;
                 if (has_ray && T.cur == REF_DONE) {
                     n_rays++;
                     if (COUNT && first_active_lane()) cnt.wave_shade++;
@@ -293,11 +342,17 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                             camera_ray(S.cam, u, v, width, height, o, d);
                             beta = v3(1.f, 1.f, 1.f);
                             depth = S.max_depth;
+                            if constexpr (LISTS) listed = has_list && round + 1 < RRT_ONE_LIST_ROUNDS;
                         } else {
                             has_ray = false;
                         }
                     }
-                    if (has_ray) trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                    if (has_ray && !(LISTS && listed)) trav_begin<MODE, SCALED>(S, o, d, __builtin_inff(), stack, RENDER_BLOCK, T);
+                }
+                if constexpr (LISTS) {
+                    if (__ballot(listed) == 0ull) break;
+                    if (listed) resolve_listed(lst, o, d, T);
+                }
                 }
                 if (__ballot(has_ray) == 0ull) break;  // every lane has rendered all samples of this item
             }
@@ -362,18 +417,8 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 if constexpr (SPLIT) { rec[6] = n_valid; rec[7] = n_long; }
             }
             if constexpr (LISTS) {
-                // the lists of the item's pixels, from the frame's list buffer to LDS: one 16-byte quarter-dozen per lane
                 // (the slot's old lists are free: nobody is on the item that held them)
-                constexpr uint32_t QUADS = PIXEL_LIST_DWORDS / 4u;
-                if (work != NO_WORK && lane < (QUADS << pix_log2)) {
-                    const uint32_t pix = lane / QUADS, quad = lane % QUADS;
-                    const uint32_t px_x = x0 + (pix & ((1u << tw_log2) - 1u)), px_y = y0 + (pix >> tw_log2);
-                    uint4 v = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);  // (a pixel outside the frame is never taken)
-                    if (px_x < width && px_y < height)
-                        v = reinterpret_cast<const uint4*>(G.lists + (size_t)(px_y * width + px_x) * PIXEL_LIST_DWORDS)[quad];
-                    uint32_t* dst = s_lists + (((threadIdx.x >> 6) * RING + slot) * (uint32_t)LIST_PIXELS + pix) * PIXEL_LIST_DWORDS + quad * 4u;
-                    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-                }
+                if (work != NO_WORK) stage_lists(slot, RING, x0, y0, pix_log2, tw_log2);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -559,19 +604,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                 if (round == 1 || __ballot(listed) == 0ull) break;
                 // the primary rays of the lanes that just started a sample of a listed pixel: closest hit over the
                 // primitives of the pixel's candidate leaves
-                if (listed) {
-                    T.best.t = __builtin_inff(); T.best.u = 0.f; T.best.v = 0.f; T.best.what = WHAT_NONE; T.best.inst = -1;
-                    T.cur = REF_DONE;
-                    const lds_u32* list = (const lds_u32*)s_lists + lst;
-                    const uint32_t n_listed = list[0];
-                    if (COUNT && first_active_lane()) cnt.wave_prims++;
-                    for (uint32_t i = 0; i < n_listed; ++i) {
-                        // (leaves in ascending order of the earliest ray parameter at which the pixel's rays can reach
-                        // them: nothing behind the hit already found needs a test)
-                        if (__uint_as_float(list[3u + 2u * i]) > T.best.t) break;
-                        test_listed_leaf<COUNT>(S, list[2u + 2u * i], o, d, S.t_min, T.best, cnt);
-                    }
-                }
+                if (listed) resolve_listed(lst, o, d, T);
             }
             }
         }

@@ -247,7 +247,7 @@ LIST_FRAMES = ((97, 55, 16, 8, 0), (97, 55, 24, 16, 5), (61, 47, 32, 32, 0), (64
 
 @pytest.mark.parametrize("name", ["default", "suzanne", "mixed", "synthetic"])
 def test_image_does_not_depend_on_pixel_lists(rrt, oracle, name):
-    """Scenes without instances, items of at most 8 pixels, two items in flight: a pass over the frame's pixels first
+    """Scenes without instances, items of at most 8 pixels, either form of the loop over items: a pass over the frame's pixels first
     collects, per pixel, the leaves whose boxes the pyramid of the pixel's camera rays touches (rrt_tuning.pixel_lists;
     at most pixel_list_len of them, else the pixel keeps walking the tree), and the pixel's primary rays test those
     leaves in order of entry distance instead of walking.  The list is a superset of the leaves any of the pixel's
@@ -260,25 +260,26 @@ def test_image_does_not_depend_on_pixel_lists(rrt, oracle, name):
     r.upload(scene)
     rc.upload(scene)
     listed_somewhere = False
-    for width, height, spp, chunks, offset in LIST_FRAMES:
-        r.set_tuning(overlap_items=1, split_items=1, chunks=chunks, pixel_lists=0)
+    for overlap, (width, height, spp, chunks, offset) in itertools.product((0, 1), LIST_FRAMES):  # both forms of the loop over items
+        r.set_tuning(overlap_items=overlap, split_items=1, chunks=chunks, pixel_lists=0)
         plain, s0 = r.render(width, height, spp, spp_offset=offset)
         for length, scaled in ((None, 1), (1, 1), (3, 0), (6, 1)):
             r.set_tuning(pixel_lists=1, pixel_list_len=length, scaled_slab=scaled)
             img, s1 = r.render(width, height, spp, spp_offset=offset)
-            assert s1.chunks == chunks and s0.rays == s1.rays and np.array_equal(plain, img), (name, width, height, spp, chunks, length)
+            assert s1.chunks == chunks and s0.rays == s1.rays and np.array_equal(plain, img), (name, overlap, width, height, spp, chunks, length)
             if length is None:
                 listed_somewhere |= r.info().pixel_list_permille > 0
         r.set_tuning(scaled_slab=None)
     assert listed_somewhere
     w, h, spp = 96, 54, 16
-    rc.set_tuning(overlap_items=1, split_items=1, chunks=8, pixel_lists=0)
-    walked, c0 = rc.render(w, h, spp)
-    rc.set_tuning(pixel_lists=1)
-    listed, c1 = rc.render(w, h, spp)
-    assert c0.rays == c1.rays and np.array_equal(walked, listed)
-    assert rc.info().pixel_list_permille > 0 and c1.node_visits < c0.node_visits
-    r.set_tuning(chunks=8, pixel_lists=1, pixel_list_len=None)
+    for overlap in (0, 1):
+        rc.set_tuning(overlap_items=overlap, split_items=1, chunks=8, pixel_lists=0)
+        walked, c0 = rc.render(w, h, spp)
+        rc.set_tuning(pixel_lists=1)
+        listed, c1 = rc.render(w, h, spp)
+        assert c0.rays == c1.rays and np.array_equal(walked, listed)
+        assert rc.info().pixel_list_permille > 0 and c1.node_visits < c0.node_visits
+    r.set_tuning(overlap_items=1, chunks=8, pixel_lists=1, pixel_list_len=None)
     img, st = r.render(w, h, spp)
     assert np.array_equal(img, listed)
     ref, ref_rays = oracle.OracleScene(scene).render(w, h, spp, seed=21)
@@ -319,9 +320,10 @@ def test_pixel_lists_with_hostile_cameras(rrt):
         for w, h, spp, chunks in ((72, 48, 16, 8), (1, 40, 32, 32), (50, 1, 16, 16)):
             r.set_tuning(overlap_items=1, split_items=1, chunks=chunks, pixel_lists=0)
             plain, s0 = r.render(w, h, spp)
-            r.set_tuning(pixel_lists=1)
-            img, s1 = r.render(w, h, spp)
-            assert s0.rays == s1.rays and np.array_equal(plain, img), (scale, offset, fov, back, cam_len, flat_axis, w, h)
+            for overlap in (0, 1):
+                r.set_tuning(overlap_items=overlap, pixel_lists=1)
+                img, s1 = r.render(w, h, spp)
+                assert s0.rays == s1.rays and np.array_equal(plain, img), (scale, offset, fov, back, cam_len, flat_axis, w, h, overlap)
         r.close()
 
 
