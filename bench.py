@@ -240,6 +240,7 @@ def main():
     if rank == 0 and not args.no_frame_check:
         renderer.render_device(width, height, spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
         st_a = renderer.render_stats()
+        listed_permille = renderer.info().pixel_list_permille
         whole = torch.empty_like(accum)
         renderer.set_tuning(chunks=st_a.chunks, split_items=0)
         renderer.render_device(width, height, spp, spp_offset, whole.data_ptr(), stream.cuda_stream)
@@ -249,7 +250,9 @@ def main():
         del whole
         if not same:
             raise SystemExit("bench.py: the timed kernel variant and the whole-tile form of the kernel disagree on this frame")
-        frame_check = f"bit-identical to whole-tile items ({st_a.chunks} sample chunks, {st_a.rays} rays)"
+        listed = listed_permille / 10.0
+        frame_check = (f"bit-identical to whole-tile items whose primary rays walk the tree ({st_a.chunks} sample chunks, {st_a.rays} rays; "
+                       f"timed variant: {listed:.1f} % of the pixels resolve their primary rays against candidate lists)")
     if grouped:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -293,6 +296,8 @@ def main():
                 # a rate, NOT a fraction of the HBM peak
                 "algorithmic_GBps": algo_bytes / k_s / 1e9,
                 # fraction of the 64 lanes doing useful work in a node step / primitive test / shading pass (software counters)
+                # share of the frame's pixels whose primary rays take a candidate list instead of a walk (k_pixel_lists)
+                "pixel_list_share": renderer.info().pixel_list_permille / 1000.0,
                 "lane_util_node": cs.node_visits / max(64 * cs.node_wave_steps, 1),
                 "lane_util_prim": cs.prim_tests / max(64 * cs.prim_wave_steps, 1),
                 "lane_util_shade": cs.rays / max(64 * cs.shade_wave_passes, 1),
@@ -342,7 +347,9 @@ def main():
                             "the number of active lanes, tools/l1_rate.hip); l1_addr_busy_frac = TA_BUSY_avr / kernel cycles is that unit's own "
                             "busy counter.  hbm: HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) / kernel time over 8 TB/s.  lane_util_hw = "
                             "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) is the share of lanes that work in an issued vector "
-                            "instruction.  algorithmic_GBps is served by the caches and is not a fraction of any peak.")
+                            "instruction.  algorithmic_GBps is served by the caches and is not a fraction of any peak.  kernel_ms is taken "
+                            "between HIP events around the launch: k_render plus the two small kernels of a launch (k_pixel_lists before it, "
+                            "k_reduce_chunks after it: 0.5 % of the time on the headline frame, profiles/round3_config4_1024spp_rocprofv3_summary.txt).")
         else:
             roof.update({"bound": "issue", "achieved": None, "peak": ISSUE_PEAK_GINST, "unit": "G wave-instructions/s (VALU)", "frac": None,
                          "traffic": None, "note": "this scene / frame size has no committed PMC profile (profiles/pmc_per_launch.json)"})
