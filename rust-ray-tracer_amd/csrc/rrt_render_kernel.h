@@ -101,6 +101,9 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_FLAT_WAVES
 #define RRT_FLAT_WAVES 7  // workgroups per CU the pipelined form is compiled for on scenes without instances
 #endif
+#ifndef RRT_RESET_RAY
+#define RRT_RESET_RAY 1  // pipelined form with pixel lists: 1 = slab constants recomputed at the start of every walk phase
+#endif
 #ifndef RRT_ONE_LIST_ROUNDS
 #define RRT_ONE_LIST_ROUNDS 2  // one-item form with pixel lists: rounds of a shade phase (the new samples of all but the last take their lists)
 #endif
@@ -462,6 +465,17 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
 
 #if RRT_WALK_PRIO || RRT_SHADE_PRIO
             __builtin_amdgcn_s_setprio(RRT_WALK_PRIO);
+#endif
+#if RRT_RESET_RAY
+            // LISTS: the slab constants of every lane's ray are formed anew from the ray at the start of each walk
+            // phase (a straggler's are the same values again): six registers that are then free during the shade phase,
+            // where the primitive tests of the lists make the kernel's register pressure peak (30 -> 26 spilled
+            // registers; 1M-triangle scene 802 -> 795 ms.  Without lists the recomputation costs more than the spills:
+            // the ten-million-triangle scenes 160 -> 166 ms.)
+            if constexpr (LISTS) {
+                if (SCALED) trav_set_ray_scaled(T, o, d, S);
+                else trav_set_ray(T, o, d, S.grid.origin, S.grid.step);
+            }
 #endif
             // ---- walk phase: node passes and leaf passes alternate until every lane's walk is complete.
             // A pass costs the same however many lanes take part, so a node pass only runs (and only keeps
