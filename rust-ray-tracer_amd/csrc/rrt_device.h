@@ -908,7 +908,24 @@ __device__ __forceinline__ bool frustum_touches_triangle(const PixelFrustum& F, 
         const float far_in = fmaxf(fmaxf(dot(n, p0), dot(n, p1)), dot(n, p2));
         in = in && (far_in >= -rho * norm1(n));
     }
-    return in;
+    if (!in) return false;
+    //   * or the pyramid lies outside one of the three planes through the apex and an edge of the triangle (the
+    //     triangle lies on one side of each, the side of its third corner): all four corner rays on the other side,
+    //     by more than the triangle's allowance rho seen from where the pyramid can first come near it (the ray
+    //     parameter there is at least z_min / amax, with z_min the triangle's least depth along the centre ray).
+    //     Together with the side planes these are all separating planes of two convex cones from one apex.
+    const float z_min = fminf(fminf(dot(F.a, p0), dot(F.a, p1)), dot(F.a, p2)) - rho * norm1(F.a);
+    if (!(z_min > 0.0f)) return true;  // the triangle reaches the apex's own depth: kept
+    const V3 m01 = cross(p0, e1), m12 = cross(p1, e2 - e1), m20 = cross(p2, -e2);
+    const float vol = dot(m01, p2);  // the same triple product for all three edges (cyclic order)
+    if (!(fabsf(vol) > 1e-5f * (norm1(m01) * norm1(p2)))) return true;  // seen edge-on: kept
+    const float sgn = vol > 0.0f ? 1.0f : -1.0f;
+    const float per_norm = rho * __builtin_amdgcn_rcpf(z_min * F.inv_amax) * 1.0001f + 2e-6f * F.d_l1;
+    auto outside = [&](V3 m) {
+        const float inmost = fmaxf(fmaxf(sgn * dot(m, F.d[0]), sgn * dot(m, F.d[1])), fmaxf(sgn * dot(m, F.d[2]), sgn * dot(m, F.d[3])));
+        return inmost < -per_norm * norm1(m);
+    };
+    return !(outside(m01) || outside(m12) || outside(m20));
 }
 // False only if the box [mn, mx] lies outside one of the pyramid's side planes (conservative: the plane test is made
 // at the box's corner furthest inside, with a relative allowance for the rounding of the sum).
