@@ -1,3 +1,5 @@
+"""Time of a 128-spp launch of the headline frame by maximum path depth, with and without pixel lists:
+    python tools/depth_split.py   (on the GPU box)"""
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, rrt_pkg, helpers, bench
