@@ -239,7 +239,9 @@ __global__ void k_add(float* __restrict__ dst, const float* __restrict__ src, si
 // `lists` (PIXEL_LIST_DWORDS dwords per pixel, row-major).  Neighbouring pixels' pyramids walk the same nodes, so the
 // lanes of a wavefront (an 8x8 block of pixels) stay together.
 // listed (one u64): the kernel adds the number of pixels that got a list.
-__global__ __launch_bounds__(256) void k_pixel_lists(SceneDev S, uint32_t width, uint32_t height, uint32_t max_len, uint32_t* __restrict__ lists,
+// (Five workgroups per CU: left to itself the kernel takes 141 registers and three wavefronts per SIMD, too few to
+// cover the walk's dependent fetches; at 102 registers it runs a fifth faster, at 64 it spills too much.)
+__global__ __launch_bounds__(256, 5) void k_pixel_lists(SceneDev S, uint32_t width, uint32_t height, uint32_t max_len, uint32_t* __restrict__ lists,
                                                      unsigned long long* __restrict__ listed) {
     const uint32_t tiles_x = (width + 7u) / 8u;
     const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
