@@ -245,8 +245,9 @@ typedef struct rrt_tuning {
     uint32_t refill_min;       /* 1..64: idle lanes that make the ray-batch kernel draw new rays                        */
     uint32_t blocks_per_cu;    /* resident workgroups per CU of the persistent kernels (at most what the kernel allows) */
     uint32_t intersect_static; /* 1: rrt_intersect runs the plain one-lane-per-ray kernel                               */
-    uint32_t pixel_lists;      /* 1: primary rays of split items resolved against per-pixel leaf lists; 0: they walk    */
-    uint32_t pixel_list_len;   /* 1..11: a pixel whose camera rays can reach more leaves than this gets no list         */
+    uint32_t pixel_lists;      /* 1: primary rays of split items resolved against per-pixel candidate lists; 0: they
+                                  walk the tree                                                                        */
+    uint32_t pixel_list_len;   /* 1..11: a pixel whose camera rays can reach more primitives than this gets no list     */
     uint32_t reserved[3];      /* RRT_TUNE_AUTO                                                                         */
 } rrt_tuning;
 

@@ -46,11 +46,11 @@ struct RenderTuning {
     // Render kernel, scenes without instances: 1: a work item is a few pixels times as many of their sample chunks as make 64 lanes
     // (all of the frame's chunks when there are at most 32); 0: 64 pixels times one chunk.  Same image either way.
     uint32_t split_items = 0u;
-    // Render kernel, split items of at most eight pixels in the pipelined form: 1: the primary rays of a pixel are
-    // resolved against a list of the leaves the pixel's pyramid of camera rays touches, collected once per work item,
-    // instead of walking the tree.  Same image either way.
+    // Render kernel, split items of at most eight pixels: 1: the primary rays of a pixel are resolved against a list of
+    // the primitives the pixel's pyramid of camera rays can meet, collected by a pass over the frame's pixels before
+    // the render kernel, instead of walking the tree.  Same image either way.
     uint32_t pixel_lists = 0u;
-    // ... a pixel whose pyramid touches more leaves than this (at most PIXEL_LIST_MAX) gets no list
+    // ... a pixel with more candidates than this (at most PIXEL_LIST_MAX) gets no list
     uint32_t pixel_list_len = PIXEL_LIST_MAX;
     // Persistent kernels: fewer resident workgroups per CU than the kernel allows (0: all of them; occupancy experiments).
     uint32_t blocks_per_cu = 0u;

@@ -186,12 +186,13 @@ struct RenderGeom {
     uint32_t n_groups;          // work items per tile (pipelined form: an item holds several consecutive chunks of its pixels)
     uint32_t pix_log2, tw_log2; // pipelined form: an item is 2^pix_log2 pixels (a tile 2^tw_log2 pixels wide) x 64 / pixels chunks
     uint32_t chunk_r;           // the first chunk_r chunks hold chunk_q + 1 samples, the others chunk_q
-    const uint32_t* lists;      // per-pixel candidate leaf lists (PIXEL_LIST_DWORDS dwords per pixel, row-major), or null
+    const uint32_t* lists;      // per-pixel candidate lists (PIXEL_LIST_DWORDS dwords per pixel, row-major), or null
 };
-// A pixel's list of candidate leaves for its primary rays, as k_pixel_lists writes it: dword 0 = number of entries (or
-// 0xFFFFFFFF: no list, the pixel's primary rays walk the tree), dword 1 unused, then per entry the leaf reference and
-// the bit pattern of a lower bound of the ray parameter at which a ray of the pixel can reach the leaf's box, in
-// ascending order of that bound.
+// A pixel's list of candidates for its primary rays, as k_pixel_lists writes it: dword 0 = number of entries (or
+// 0xFFFFFFFF: no list, the pixel's primary rays walk the tree), dword 1 unused, then per entry a leaf reference (a
+// triangle as a triangle leaf of one; a sphere or rectangle leaf as it is) and the bit pattern of a lower bound of the
+// ray parameter at which a ray of the pixel can reach the box of the leaf the entry came from, in ascending order of
+// that bound.
 static constexpr uint32_t PIXEL_LIST_MAX = 11u;
 static constexpr uint32_t PIXEL_LIST_DWORDS = 2u * (PIXEL_LIST_MAX + 1u);
 // First sample (relative to the launch's first) and length of chunk c of a launch cut as RenderGeom describes.

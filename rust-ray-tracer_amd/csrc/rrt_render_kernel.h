@@ -115,10 +115,10 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 // SPLIT (scenes without instances): an item's 64 lanes are 2^G.pix_log2 pixels times several of their
 // sample chunks instead of 64 pixels times one (launch_render picks the split); a template parameter because the
 // general index arithmetic costs the other scenes 1-3 % when it is merely switched off at run time.
-// LISTS (split items of at most LIST_PIXELS pixels, pipelined form, scenes without instances): a kernel run before this one
-// (k_pixel_lists) has collected, for every pixel, the leaves the pixel's pyramid of camera rays touches.  When a
+// LISTS (split items of at most LIST_PIXELS pixels, scenes without instances): a kernel run before this one
+// (k_pixel_lists) has collected, for every pixel, the primitives a camera ray of the pixel can hit.  When a
 // wavefront draws an item it copies the lists of the item's pixels to LDS; a lane that starts a sample of a pixel with a
-// list resolves its primary ray against that list inside the shading phase -- a handful of primitive tests instead of a
+// list resolves its primary ray against that list inside the shading phase -- a couple of primitive tests instead of a
 // walk -- and shades it in a second round of the same phase, so that the walk phase of a trip carries bounce rays
 // only and a sample costs one trip less.
 static constexpr int LIST_PIXELS = 8;   // pixels of an item that get a list
