@@ -232,6 +232,10 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+    # The library times the first launches of a frame geometry to choose between two builds of its render kernel (six or
+    # seven wavefronts per SIMD; rrt_tuning.list_waves): three launches until the choice stands, whatever --warmup says.
+    for _ in range(max(0, 3 - args.warmup)):
+        step(False)
     # One more untimed step on rank 0: the frame as the timed steps render it (on scenes without instances: work items of
     # a few pixels x many sample chunks) against the same sample slice rendered with whole 8x8 tiles as items.  Every
     # pixel's chunk sums are formed by one lane in sample order either way, so the two must agree in every bit and in

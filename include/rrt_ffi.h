@@ -248,7 +248,10 @@ typedef struct rrt_tuning {
     uint32_t pixel_lists;      /* 1: primary rays of split items resolved against per-pixel candidate lists; 0: they
                                   walk the tree                                                                        */
     uint32_t pixel_list_len;   /* 1..11: a pixel whose camera rays can reach more primitives than this gets no list     */
-    uint32_t reserved[3];      /* RRT_TUNE_AUTO                                                                         */
+    uint32_t list_waves;       /* 6 or 7: wavefronts per SIMD the render kernel with pixel lists is compiled for (84 or
+                                  72 registers).  RRT_TUNE_AUTO: the library times both on the scene's first launches of
+                                  a frame size and sample count whose statistics are read, and keeps the faster one     */
+    uint32_t reserved[2];      /* RRT_TUNE_AUTO                                                                         */
 } rrt_tuning;
 
 /* ---- lifetime ----  replaces: process start-up in reference src/main.rs:26-56 */

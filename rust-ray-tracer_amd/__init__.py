@@ -131,7 +131,7 @@ class Tuning(C.Structure):
                 ("leave_walk", C.c_uint32), ("leave_ready", C.c_uint32), ("overlap_items", C.c_uint32),
                 ("band_tiles", C.c_uint32), ("scaled_slab", C.c_uint32), ("refill_min", C.c_uint32),
                 ("blocks_per_cu", C.c_uint32), ("intersect_static", C.c_uint32), ("pixel_lists", C.c_uint32),
-                ("pixel_list_len", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("pixel_list_len", C.c_uint32), ("list_waves", C.c_uint32), ("reserved", C.c_uint32 * 2)]
 
 
 class SceneInfo(C.Structure):

@@ -82,6 +82,7 @@ rrt_tuning tuning_from_env() {
     t.intersect_static = env_u32("RRT_INTERSECT_STATIC", 0u, 1u);
     t.pixel_lists = env_u32("RRT_PIXEL_LISTS", 0u, 1u);
     t.pixel_list_len = env_u32("RRT_PIXEL_LIST_LEN", 1u, PIXEL_LIST_MAX);
+    t.list_waves = env_u32("RRT_LIST_WAVES", 6u, 7u);
     for (uint32_t& r : t.reserved) r = RRT_TUNE_AUTO;
     return t;
 }
@@ -89,7 +90,7 @@ rrt_tuning clamp_tuning(rrt_tuning t) {
     auto cl = [](uint32_t& v, uint32_t lo, uint32_t hi) { if (v != RRT_TUNE_AUTO) v = std::max(lo, std::min(hi, v)); };
     cl(t.chunks, 1u, 0x7FFFFFFFu); cl(t.split_items, 0u, 1u); cl(t.node_share_64ths, 0u, 64u); cl(t.leave_walk, 0u, 63u);
     cl(t.leave_ready, 1u, 64u); cl(t.overlap_items, 0u, 1u); cl(t.band_tiles, 0u, 0x7FFFFFFFu); cl(t.scaled_slab, 0u, 1u);
-    cl(t.refill_min, 1u, 64u); cl(t.blocks_per_cu, 1u, 64u); cl(t.intersect_static, 0u, 1u); cl(t.pixel_lists, 0u, 1u); cl(t.pixel_list_len, 1u, PIXEL_LIST_MAX);
+    cl(t.refill_min, 1u, 64u); cl(t.blocks_per_cu, 1u, 64u); cl(t.intersect_static, 0u, 1u); cl(t.pixel_lists, 0u, 1u); cl(t.pixel_list_len, 1u, PIXEL_LIST_MAX); cl(t.list_waves, 6u, 7u);
     for (uint32_t& r : t.reserved) r = RRT_TUNE_AUTO;
     return t;
 }
@@ -126,6 +127,15 @@ struct rrt_ctx {
     // share of the pixels that got a list in the last such render whose statistics were read (1.0: not known yet);
     // reset by a scene upload
     float list_share = 1.0f;
+    // The render kernel with lists exists compiled for 7 and for 6 wavefronts per SIMD, and which is faster depends on
+    // the scene: the launches of one frame geometry (width, height, samples) run 7 (the first launch, which also
+    // warms the caches: not timed), then 6, then 7 again, and from then on the one whose launch was faster.  A launch
+    // counts once its statistics (the kernel time) are read.  [0]: 7, [1]: 6; 0: not measured.  Reset by a scene upload
+    // and by another frame geometry.
+    float waves_ms[2] = {0.0f, 0.0f};
+    uint32_t waves_key[3] = {0u, 0u, 0u};
+    uint32_t waves_launches = 0;  // launches of this geometry whose time was read
+    int pending_waves = -1;  // which of the two the pending render runs (index into waves_ms), -1: neither
 };
 
 namespace {
@@ -434,6 +444,8 @@ static rrt_status scene_upload_impl(rrt_ctx* c, const rrt_scene_desc* scene, Hos
     c->info.upload_ms = upload_ms;
     c->info.pixel_list_permille = 0u;
     c->list_share = 1.0f;
+    c->waves_ms[0] = c->waves_ms[1] = 0.0f;
+    c->waves_launches = 0u;
     c->has_scene = true;
     return RRT_OK;
 }
@@ -517,6 +529,7 @@ rrt_status rrt_intersect_device(rrt_ctx* c, const rrt_ray* d_rays, size_t n, flo
     c->pending_rays = n;
     c->pending_chunks = 0;
     c->pending_list_pixels = 0;
+    c->pending_waves = -1;
     c->last_counters = c->d_counters;
     return RRT_OK;
 }
@@ -673,6 +686,18 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // taken from the scene's last render whose statistics were read; until one was, every pixel is assumed to.
     tuning.pixel_lists = tn.pixel_lists != RRT_TUNE_AUTO ? tn.pixel_lists : (lists_possible && (float)spp * c->list_share >= 32.0f ? 1u : 0u);
     if (tn.pixel_list_len != RRT_TUNE_AUTO) tuning.pixel_list_len = tn.pixel_list_len;
+    int waves_slot = -1;
+    if (tn.list_waves != RRT_TUNE_AUTO) {
+        tuning.list_waves = tn.list_waves;
+    } else if (tuning.pixel_lists != 0u && tuning.overlap_items != 0u) {
+        if (c->waves_key[0] != width || c->waves_key[1] != height || c->waves_key[2] != spp) {
+            c->waves_key[0] = width; c->waves_key[1] = height; c->waves_key[2] = spp;
+            c->waves_ms[0] = c->waves_ms[1] = 0.0f;
+            c->waves_launches = 0u;
+        }
+        waves_slot = c->waves_launches == 0u ? 0 : (c->waves_ms[1] == 0.0f ? 1 : (c->waves_ms[0] == 0.0f ? 0 : (c->waves_ms[1] < c->waves_ms[0] ? 1 : 0)));
+        tuning.list_waves = waves_slot == 1 ? 6u : 7u;
+    }
     // per-pixel candidate leaf lists for the primary rays (launch_render): a frame-sized buffer of the context, grown on
     // demand; the entry point that may not allocate goes without them
     uint32_t* d_lists = nullptr;
@@ -701,6 +726,7 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     c->pending_rays = 0;
     c->pending_chunks = n_chunks;
     c->pending_list_pixels = d_lists ? pixels : 0u;
+    c->pending_waves = d_lists ? waves_slot : -1;
     c->last_counters = d_counters;
     return RRT_OK;
 }
@@ -739,6 +765,11 @@ rrt_status rrt_render_stats(rrt_ctx* c, rrt_stats* stats) {
     stats->samples = c->pending_samples;
     stats->kernel_ms = ms;
     stats->chunks = c->pending_chunks;
+    if (c->pending_waves >= 0) {
+        if (c->waves_launches != 0u && c->waves_ms[c->pending_waves] == 0.0f && ms > 0.0f) c->waves_ms[c->pending_waves] = ms;
+        c->waves_launches++;
+    }
+    c->pending_waves = -1;
     if (c->pending_list_pixels != 0u) {
         c->list_share = (float)((double)h[14] / (double)c->pending_list_pixels);
         c->info.pixel_list_permille = (uint32_t)(c->list_share * 1000.0f + 0.5f);

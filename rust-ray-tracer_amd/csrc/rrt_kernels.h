@@ -52,6 +52,9 @@ struct RenderTuning {
     uint32_t pixel_lists = 0u;
     // ... a pixel with more candidates than this (at most PIXEL_LIST_MAX) gets no list
     uint32_t pixel_list_len = PIXEL_LIST_MAX;
+    // ... the pipelined form with lists as compiled for 7 workgroups per CU (72 registers, some of them spilled) or for
+    // 6 (84 registers): same image, and which one is faster depends on the scene
+    uint32_t list_waves = 7u;
     // Persistent kernels: fewer resident workgroups per CU than the kernel allows (0: all of them; occupancy experiments).
     uint32_t blocks_per_cu = 0u;
     // Ray batches: 1 runs the plain one-lane-per-ray kernel instead of the streaming one (experiments).

@@ -356,7 +356,12 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
                            std::min(tuning.pixel_list_len, PIXEL_LIST_MAX), d_lists, d_counters + 14);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         G.lists = d_lists;
-        switch ((scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {
+        const bool roomy = pipelined && tuning.list_waves == 6u;
+        switch ((roomy ? 8u : 0u) | (scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {
+            case 15u: e = launch_render_variant<MODE_FLAT, true, true, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 13u: e = launch_render_variant<MODE_FLAT, false, true, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 11u: e = launch_render_variant<MODE_FLAT, true, true, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
+            case 9u: e = launch_render_variant<MODE_FLAT, false, true, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
             case 7u: e = launch_render_variant<MODE_FLAT, true, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
             case 6u: e = launch_render_variant<MODE_FLAT, true, false, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
             case 5u: e = launch_render_variant<MODE_FLAT, false, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;

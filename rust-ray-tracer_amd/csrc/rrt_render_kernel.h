@@ -122,13 +122,18 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 // walk -- and shades it in a second round of the same phase, so that the walk phase of a trip carries bounce rays
 // only and a sample costs one trip less.
 static constexpr int LIST_PIXELS = 8;   // pixels of an item that get a list
-template <int MODE, bool COUNT, bool PIPELINED, bool SCALED, bool SPLIT = false, bool LISTS = false>
-__global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? RRT_UNROLLED_WAVES : RRT_FLAT_WAVES) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+// ROOMY (pipelined form with lists): compiled for six workgroups per CU instead of seven -- 84 registers, which the
+// shade phase with a list's primitive tests in it needs to stay out of scratch memory.  Which of the two is faster
+// depends on the scene (measured on MI355X: the 1M-triangle scene 764 -> 740 ms with six, MetalRoughSpheres 258 -> 262):
+// the caller chooses (RenderTuning::list_waves).
+template <int MODE, bool COUNT, bool PIPELINED, bool SCALED, bool SPLIT = false, bool LISTS = false, bool ROOMY = false>
+__global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? RRT_UNROLLED_WAVES : (ROOMY ? RRT_FLAT_WAVES - 1 : RRT_FLAT_WAVES)) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
     constexpr bool INST = MODE == MODE_TWO_LEVEL;
     static_assert(!(SCALED && INST), "the scaled slab arithmetic is for scenes walked on one grid");
     static_assert(!LISTS || (SPLIT && MODE == MODE_FLAT), "pixel lists: split items, no instances");
+    static_assert(!ROOMY || (LISTS && PIPELINED), "the six-workgroup build is for the pipelined form with lists");
     __shared__ __align__(16) uint32_t s_lists[LISTS ? (RENDER_BLOCK / WAVE) * (PIPELINED ? RRT_ITEM_RING : 1) * LIST_PIXELS * PIXEL_LIST_DWORDS : 1];
     // RENDER_STACK entries per lane of the traversal stack live in LDS, the rest in private memory (six workgroups per
     // CU, seven in the pipelined form, whose large scenes gain more from the extra wavefront than they lose to its
@@ -656,19 +661,19 @@ static hipError_t resident_blocks_per_cu(Kernel kernel, std::atomic<int>& cache,
 }
 
 // max_blocks_per_cu: 0, or fewer resident workgroups per CU than the kernel allows (RenderTuning::blocks_per_cu).
-template <int MODE, bool COUNT, bool PIPELINED, bool SCALED = false, bool SPLIT = false, bool LISTS = false>
+template <int MODE, bool COUNT, bool PIPELINED, bool SCALED = false, bool SPLIT = false, bool LISTS = false, bool ROOMY = false>
 static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, float* out, unsigned long long* d_counters,
                                         unsigned int* d_heads, int cu_count, uint32_t max_blocks_per_cu, hipStream_t stream) {
     // persistent grid: as many workgroups as the chip holds at once (never more than there are work items)
     static std::atomic<int> cache{0};
     int blocks_per_cu = 1;
-    if (hipError_t e = resident_blocks_per_cu(k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT, LISTS>, cache, blocks_per_cu); e != hipSuccess) return e;
+    if (hipError_t e = resident_blocks_per_cu(k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT, LISTS, ROOMY>, cache, blocks_per_cu); e != hipSuccess) return e;
     if (max_blocks_per_cu != 0u && (int)max_blocks_per_cu < blocks_per_cu) blocks_per_cu = (int)max_blocks_per_cu;
     unsigned long long blocks = (unsigned long long)blocks_per_cu * (unsigned)cu_count;
     const unsigned long long needed = ((unsigned long long)G.n_work + 3ull) / 4ull;
     if (blocks > needed) blocks = needed;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT, LISTS>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
+    hipLaunchKernelGGL((k_render<MODE, COUNT, PIPELINED, SCALED, SPLIT, LISTS, ROOMY>), dim3((unsigned)blocks), dim3(RENDER_BLOCK), 0, stream, S, G, out, d_counters, d_heads);
     return hipGetLastError();
 }
 

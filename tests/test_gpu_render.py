@@ -263,13 +263,13 @@ def test_image_does_not_depend_on_pixel_lists(rrt, oracle, name):
     for overlap, (width, height, spp, chunks, offset) in itertools.product((0, 1), LIST_FRAMES):  # both forms of the loop over items
         r.set_tuning(overlap_items=overlap, split_items=1, chunks=chunks, pixel_lists=0)
         plain, s0 = r.render(width, height, spp, spp_offset=offset)
-        for length, scaled in ((None, 1), (1, 1), (3, 0), (6, 1)):
-            r.set_tuning(pixel_lists=1, pixel_list_len=length, scaled_slab=scaled)
+        for length, scaled, waves in ((None, 1, None), (1, 1, 7), (3, 0, 6), (6, 1, 6)):  # (waves: the kernel's two register budgets)
+            r.set_tuning(pixel_lists=1, pixel_list_len=length, scaled_slab=scaled, list_waves=waves)
             img, s1 = r.render(width, height, spp, spp_offset=offset)
             assert s1.chunks == chunks and s0.rays == s1.rays and np.array_equal(plain, img), (name, overlap, width, height, spp, chunks, length)
             if length is None:
                 listed_somewhere |= r.info().pixel_list_permille > 0
-        r.set_tuning(scaled_slab=None)
+        r.set_tuning(scaled_slab=None, list_waves=None)
     assert listed_somewhere
     w, h, spp = 96, 54, 16
     for overlap in (0, 1):

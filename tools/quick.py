@@ -36,7 +36,7 @@ def main():
     for spp in [int(x) for x in args.spp.split(",")]:
         first_img, first_rays = None, None
         for t in sets:
-            knobs = {k: None for k in ("chunks", "split_items", "node_share_64ths", "leave_walk", "leave_ready", "overlap_items", "band_tiles", "scaled_slab", "blocks_per_cu", "pixel_lists", "pixel_list_len")}
+            knobs = {k: None for k in ("chunks", "split_items", "node_share_64ths", "leave_walk", "leave_ready", "overlap_items", "band_tiles", "scaled_slab", "blocks_per_cu", "pixel_lists", "pixel_list_len", "list_waves")}
             for kv in filter(None, t.split(",")):
                 k, v = kv.split("=")
                 knobs[k] = int(v)
