@@ -862,12 +862,26 @@ struct PixelFrustum {
     V3 a;           // the ray through the pixel's centre
     float inv_amax; // 1 / the largest a . d over the pyramid's rays d (attained at a corner: a . d is affine over the pixel)
     float d_l1;     // the largest 1-norm of a corner ray
+    bool ok;        // false: the camera arithmetic is too coarse for a pyramid of this pixel to mean anything (no list)
 };
 __device__ __forceinline__ PixelFrustum pixel_frustum(const CameraRec& cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
-    // the jittered coordinates of the pixel lie in [px, px + 1] x [py, py + 1]; 1/64 of a pixel of slack on every side
-    // covers the rounding of the camera arithmetic many times over
-    const float e = 1.0f / 64.0f, x0 = (float)px - e, x1 = (float)px + 1.0f + e, y0 = (float)py - e, y1 = (float)py + 1.0f + e;
+    // The jittered coordinates of the pixel lie in [px, px + 1] x [py, py + 1].  Slack on every side: 1/64 of a pixel,
+    // plus what the rounding of camera_ray can move a ray (and the corner rays formed here) across the image plane:
+    // ray_p is rounded at the magnitude of the camera's position, however short the camera's axes are, i.e. each of
+    // its components is off by up to an ulp of |translation| + |axes|.  That error vector, written in the basis of the
+    // axes, is a shift of the ray's image-plane coordinates (its part along the view axis rescales them).
+    const V3 q0 = v3(cam.c0[0], cam.c0[1], cam.c0[2]), q1 = v3(cam.c1[0], cam.c1[1], cam.c1[2]), q2 = v3(cam.c2[0], cam.c2[1], cam.c2[2]);
+    const float ax = fabsf(cam.scale * cam.aspect), ay = fabsf(cam.scale);
+    const float err = 2.5e-7f * fmaxf(fmaxf(fabsf(cam.tr[0]) + fabsf(q0.x) * ax + fabsf(q1.x) * ay + fabsf(q2.x),
+                                            fabsf(cam.tr[1]) + fabsf(q0.y) * ax + fabsf(q1.y) * ay + fabsf(q2.y)),
+                                      fabsf(cam.tr[2]) + fabsf(q0.z) * ax + fabsf(q1.z) * ay + fabsf(q2.z));
+    const V3 r0 = cross(q1, q2), r1 = cross(q2, q0), r2 = cross(q0, q1);  // rows of the inverse of (q0 q1 q2), times its determinant
+    const float inv_det = 1.0f / fabsf(dot(q0, r0));
+    const float ex = 1.0f / 64.0f + err * inv_det * (norm1(r0) + ax * norm1(r2)) * (float)w / (2.0f * ax);
+    const float ey = 1.0f / 64.0f + err * inv_det * (norm1(r1) + ay * norm1(r2)) * (float)h / (2.0f * ay);
+    const float x0 = (float)px - ex, x1 = (float)px + 1.0f + ex, y0 = (float)py - ey, y1 = (float)py + 1.0f + ey;
     PixelFrustum F;
+    F.ok = ex < 2.0f && ey < 2.0f;  // (also false for NaN: a singular camera matrix)
     V3 d00, d10, d11, d01, o;
     camera_ray(cam, x0, y0, w, h, F.o, d00);
     camera_ray(cam, x1, y0, w, h, o, d10);

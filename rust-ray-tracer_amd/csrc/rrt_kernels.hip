@@ -250,7 +250,10 @@ __global__ __launch_bounds__(256, 5) void k_pixel_lists(SceneDev S, uint32_t wid
     uint32_t refs[PIXEL_LIST_MAX];
     float entry[PIXEL_LIST_MAX];
     uint32_t n = 0xFFFFFFFFu;
-    if (inside) n = frustum_leaves<(int)PIXEL_LIST_MAX>(S, pixel_frustum(S.cam, x, y, width, height), max_len, refs, entry);
+    if (inside) {
+        const PixelFrustum F = pixel_frustum(S.cam, x, y, width, height);
+        if (F.ok) n = frustum_leaves<(int)PIXEL_LIST_MAX>(S, F, max_len, refs, entry);
+    }
     const unsigned long long got = __ballot(inside && n != 0xFFFFFFFFu);
     if (lane == 0u && got != 0ull) atomicAdd(listed, (unsigned long long)__popcll(got));
     if (!inside) return;

@@ -293,12 +293,17 @@ def test_pixel_lists_with_hostile_cameras(rrt):
     """Per-pixel leaf lists where the pyramid of a pixel's rays is awkward: a camera inside the geometry (boxes that
     contain the apex), a field of view of 170 degrees (pyramid faces almost in one plane) and of 0.2 degrees (almost
     parallel faces), geometry far from the origin and tiny, flat geometry seen edge-on, a camera matrix scaled by 1e-3
-    and 1e3, and a frame one pixel wide.  Same rays and images as without lists, bit for bit."""
+    and 1e3, a camera whose position is 1e5 times the length of its axes, and a frame one pixel wide.  Same rays and
+    images as without lists, bit for bit.  (tools/stress_lists.py runs thousands of random cases of this kind.)"""
     g = np.random.default_rng(5)
     cases = [(1.0, 0.0, 40.0, 3.0, 1.0, None), (1.0, 0.0, 60.0, 0.0, 1.0, None), (1.0, 0.0, 170.0, 1.5, 1.0, None),
              (1.0, 0.0, 0.2, 40.0, 1.0, None), (1e-3, 2e3, 40.0, 3.0, 1.0, None), (1e3, -5e4, 40.0, 3.0, 1.0, None),
              (1.0, 0.0, 40.0, 3.0, 1e-3, None), (1.0, 0.0, 40.0, 3.0, 1e3, None), (1.0, 0.0, 40.0, 3.0, 1.0, 1),
-             (1.0, 0.0, 40.0, 3.0, 1.0, 2)]
+             (1.0, 0.0, 40.0, 3.0, 1.0, 2),
+             # camera axes far shorter than the camera's distance from the origin: camera.rs:62 rounds the ray's end point at
+             # the magnitude of the position, so a pixel's rays scatter over several pixels' pyramids
+             (600.0, 0.0, 5.0, 4.0, 0.011, None), (1.0, 1e4, 5.0, 3.0, 0.3, None), (150.0, 0.0, 90.0, 0.5, 0.0107, None),
+             (30.0, 0.0, 0.5, 40.0, 1.77, None)]
     for scale, offset, fov, back, cam_len, flat_axis in cases:
         n = 3000
         centres = g.uniform(-1, 1, (n, 1, 3)) * scale
