@@ -13,20 +13,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", type=int, default=300)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", type=int, default=-1, help="render this case only, and compare both renders with the oracle's")
-    args = ap.parse_args()
+def run(cases, seed, only=-1, verbose=True):
     import numpy as np
     import rrt_pkg
 
     rrt = rrt_pkg.load()
-    g = np.random.default_rng(args.seed)
+    g = np.random.default_rng(seed)
     bad = 0
     listed_total = 0
-    for case in range(args.cases):
+    for case in range(cases):
         n = int(10 ** g.uniform(1.3, 4.3))
         scale = 10 ** g.uniform(-2, 3)
         offset = g.uniform(-1, 1, 3) * scale * 10 ** g.uniform(-1, 2)
@@ -66,10 +61,10 @@ def main():
         s.camera = rrt.Camera(float(g.uniform(0.5, 2.0)), fov, c2w)
         w, h = int(g.integers(1, 91)), int(g.integers(1, 91))
         spp, chunks = (16, 8) if g.integers(0, 2) else (37, 16)
-        seed = int(g.integers(1, 1 << 30))
-        if args.only >= 0 and case != args.only:
+        case_seed = int(g.integers(1, 1 << 30))
+        if only >= 0 and case != only:
             continue
-        r = rrt.Renderer(seed=seed)
+        r = rrt.Renderer(seed=case_seed)
         r.upload(s)
         r.set_tuning(overlap_items=1, split_items=1, chunks=chunks, pixel_lists=0)
         plain, s0 = r.render(w, h, spp)
@@ -81,16 +76,25 @@ def main():
                 print(f"MISMATCH case {case}: n {n} scale {scale:.3g} kind {kind} dist {dist:.3g} fov {fov} cam_len {cam_len:.3g} {w}x{h} spp {spp} overlap {overlap} waves {waves}: "
                       f"rays {s0.rays} / {s1.rays}, {int((plain != img).any(axis=-1).sum())} pixels differ", flush=True)
         listed_total += r.info().pixel_list_permille
-        if args.only >= 0:
+        if only >= 0:
             from oracle import oracle
-            ref, ref_rays = oracle.OracleScene(s).render(w, h, spp, seed=seed)
+            ref, ref_rays = oracle.OracleScene(s).render(w, h, spp, seed=case_seed)
             near = lambda a: int((~np.isclose(a, ref, rtol=1e-4, atol=1e-5).all(axis=-1)).sum())
             print(f"case {case}: oracle rays {ref_rays}, walked {s0.rays} ({near(plain)} pixels off the oracle's), with lists {s1.rays} ({near(img)} pixels off)")
         r.close()
-        if case % 25 == 24:
+        if verbose and case % 25 == 24:
             print(f"{case + 1} cases, {bad} mismatches, mean listed share {listed_total / (case + 1) / 10:.1f} %", flush=True)
-    print(f"done: {args.cases} cases, {bad} mismatches")
-    sys.exit(1 if bad else 0)
+    print(f"done: {cases} cases, {bad} mismatches")
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", type=int, default=-1, help="render this case only, and compare both renders with the oracle's")
+    args = ap.parse_args()
+    sys.exit(1 if run(args.cases, args.seed, args.only) else 0)
 
 
 if __name__ == "__main__":
