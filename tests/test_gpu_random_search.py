@@ -38,3 +38,13 @@ def test_pixel_lists_give_the_same_image_on_random_scenes():
     import stress_lists
 
     assert stress_lists.run(300, 7, verbose=False) == 0
+
+
+def test_same_seed_frames_match_the_oracle_on_random_scenes():
+    """Small same-seed frames (all four material kinds, a sphere light, 1 .. 6 samples) against the CPU oracle on about
+    130 random scenes and cameras: ray counts within 0.5 %, at least 95 % of the pixels within 1e-4 relative (measured
+    over a thousand such frames: all but two have at least 97 %, the lowest 95.6 % at a 175-degree field of view), the
+    tone map bit-exact."""
+    import stress_render
+
+    assert stress_render.run(200, 2, verbose=False) == 0

@@ -13,6 +13,48 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def random_flat_scene(rrt, np, g):
+    """A random scene without instances under a random camera; returns (scene, description of the draw)."""
+    n = int(10 ** g.uniform(1.3, 4.3))
+    scale = 10 ** g.uniform(-2, 3)
+    offset = g.uniform(-1, 1, 3) * scale * 10 ** g.uniform(-1, 2)
+    centres = g.uniform(-1, 1, (n, 1, 3)) * scale
+    size = scale * 10 ** g.uniform(-2.5, 0.3, (n, 1, 1))
+    tris = centres + g.normal(0, 1, (n, 3, 3)) * size
+    kind = g.integers(0, 4)
+    if kind == 1:  # needles: two corners close together
+        tris[:, 1] = tris[:, 0] + (tris[:, 1] - tris[:, 0]) * 1e-3
+    elif kind == 2:  # a flat sheet with holes
+        tris[..., g.integers(0, 3)] *= 1e-4
+    tris = (tris + offset).astype(np.float32)
+    s = rrt.Scene()
+    mats = [s.add_material(rrt.Lambertian(0.7, 0.6, 0.5)), s.add_material(rrt.Metal((0.8, 0.8, 0.9), 0.1)),
+            s.add_material(rrt.Dielectric(1.5)), s.add_material(rrt.DiffuseLight(3.0, 3.0, 3.0))]
+    cut = sorted(g.integers(0, n + 1, 2))
+    s.add_triangles(tris[: cut[0]], mats[0])
+    s.add_triangles(tris[cut[0]: cut[1]], mats[1])
+    s.add_triangles(tris[cut[1]:], mats[2])
+    for _ in range(int(g.integers(0, 4))):
+        s.add_sphere(tuple(offset + g.uniform(-1, 1, 3) * scale), float(scale * 10 ** g.uniform(-2, -0.3)), mats[int(g.integers(0, 4))])
+    if g.integers(0, 2):
+        k = float(offset[1] - scale)
+        s.add_rect(1, float(offset[0] - scale), float(offset[0] + scale), float(offset[2] - scale), float(offset[2] + scale), k, mats[0])
+    light_c = offset + np.float32([0, 2.5 * scale, 0])
+    s.add_sphere(tuple(light_c), float(0.3 * scale), mats[3])
+    s.add_sphere_light(tuple(light_c), float(0.3 * scale))
+    s.background = (0.5, 0.6, 0.8)
+    # camera: a random rotation, at a random distance (0: inside, at the centre of the soup)
+    q = g.normal(0, 1, (3, 3))
+    rot, _ = np.linalg.qr(q)
+    dist = scale * float(g.choice([0.0, 0.01, 0.5, 1.5, 4.0, 40.0]))
+    cam_len = float(10 ** g.uniform(-2, 2))
+    pos = offset + rot[:, 2] * dist
+    c2w = np.concatenate([rot * cam_len, pos[:, None]], axis=1).astype(np.float32)
+    fov = float(g.choice([0.5, 5.0, 40.0, 90.0, 150.0, 175.0]))
+    s.camera = rrt.Camera(float(g.uniform(0.5, 2.0)), fov, c2w)
+    return s, f"n {n} scale {scale:.3g} kind {kind} dist {dist:.3g} fov {fov} cam_len {cam_len:.3g}"
+
+
 def run(cases, seed, only=-1, verbose=True):
     import numpy as np
     import rrt_pkg
@@ -22,43 +64,7 @@ def run(cases, seed, only=-1, verbose=True):
     bad = 0
     listed_total = 0
     for case in range(cases):
-        n = int(10 ** g.uniform(1.3, 4.3))
-        scale = 10 ** g.uniform(-2, 3)
-        offset = g.uniform(-1, 1, 3) * scale * 10 ** g.uniform(-1, 2)
-        centres = g.uniform(-1, 1, (n, 1, 3)) * scale
-        size = scale * 10 ** g.uniform(-2.5, 0.3, (n, 1, 1))
-        tris = centres + g.normal(0, 1, (n, 3, 3)) * size
-        kind = g.integers(0, 4)
-        if kind == 1:  # needles: two corners close together
-            tris[:, 1] = tris[:, 0] + (tris[:, 1] - tris[:, 0]) * 1e-3
-        elif kind == 2:  # a flat sheet with holes
-            tris[..., g.integers(0, 3)] *= 1e-4
-        tris = (tris + offset).astype(np.float32)
-        s = rrt.Scene()
-        mats = [s.add_material(rrt.Lambertian(0.7, 0.6, 0.5)), s.add_material(rrt.Metal((0.8, 0.8, 0.9), 0.1)),
-                s.add_material(rrt.Dielectric(1.5)), s.add_material(rrt.DiffuseLight(3.0, 3.0, 3.0))]
-        cut = sorted(g.integers(0, n + 1, 2))
-        s.add_triangles(tris[: cut[0]], mats[0])
-        s.add_triangles(tris[cut[0]: cut[1]], mats[1])
-        s.add_triangles(tris[cut[1]:], mats[2])
-        for _ in range(int(g.integers(0, 4))):
-            s.add_sphere(tuple(offset + g.uniform(-1, 1, 3) * scale), float(scale * 10 ** g.uniform(-2, -0.3)), mats[int(g.integers(0, 4))])
-        if g.integers(0, 2):
-            k = float(offset[1] - scale)
-            s.add_rect(1, float(offset[0] - scale), float(offset[0] + scale), float(offset[2] - scale), float(offset[2] + scale), k, mats[0])
-        light_c = offset + np.float32([0, 2.5 * scale, 0])
-        s.add_sphere(tuple(light_c), float(0.3 * scale), mats[3])
-        s.add_sphere_light(tuple(light_c), float(0.3 * scale))
-        s.background = (0.5, 0.6, 0.8)
-        # camera: a random rotation, at a random distance (0: inside, at the centre of the soup)
-        q = g.normal(0, 1, (3, 3))
-        rot, _ = np.linalg.qr(q)
-        dist = scale * float(g.choice([0.0, 0.01, 0.5, 1.5, 4.0, 40.0]))
-        cam_len = float(10 ** g.uniform(-2, 2))
-        pos = offset + rot[:, 2] * dist
-        c2w = np.concatenate([rot * cam_len, pos[:, None]], axis=1).astype(np.float32)
-        fov = float(g.choice([0.5, 5.0, 40.0, 90.0, 150.0, 175.0]))
-        s.camera = rrt.Camera(float(g.uniform(0.5, 2.0)), fov, c2w)
+        s, what = random_flat_scene(rrt, np, g)
         w, h = int(g.integers(1, 91)), int(g.integers(1, 91))
         spp, chunks = (16, 8) if g.integers(0, 2) else (37, 16)
         case_seed = int(g.integers(1, 1 << 30))
@@ -73,7 +79,7 @@ def run(cases, seed, only=-1, verbose=True):
             img, s1 = r.render(w, h, spp)
             if not (s0.rays == s1.rays and np.array_equal(plain, img)):
                 bad += 1
-                print(f"MISMATCH case {case}: n {n} scale {scale:.3g} kind {kind} dist {dist:.3g} fov {fov} cam_len {cam_len:.3g} {w}x{h} spp {spp} overlap {overlap} waves {waves}: "
+                print(f"MISMATCH case {case}: {what} {w}x{h} spp {spp} overlap {overlap} waves {waves}: "
                       f"rays {s0.rays} / {s1.rays}, {int((plain != img).any(axis=-1).sum())} pixels differ", flush=True)
         listed_total += r.info().pixel_list_permille
         if only >= 0:
