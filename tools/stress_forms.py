@@ -23,6 +23,45 @@ def camera(rrt, np, g, centre, scale):
     return rrt.Camera(float(g.uniform(0.5, 2.0)), float(g.choice([0.5, 5.0, 40.0, 90.0, 150.0, 175.0])), c2w)
 
 
+def random_scene(rrt, np, g, instanced):
+    """A random scene (with instanced meshes if asked) under a random camera; returns (scene, triangles drawn, scale)."""
+    scale = 10 ** g.uniform(-2, 3)
+    offset = g.uniform(-1, 1, 3) * scale * 10 ** g.uniform(-1, 2)
+    s = rrt.Scene()
+    mats = [s.add_material(rrt.Lambertian(0.7, 0.6, 0.5)), s.add_material(rrt.Metal((0.8, 0.8, 0.9), 0.1)),
+            s.add_material(rrt.Dielectric(1.5)), s.add_material(rrt.DiffuseLight(3.0, 3.0, 3.0))]
+    n = int(10 ** g.uniform(1.3, 3.7 if instanced else 4.3))
+    size = scale * 10 ** g.uniform(-2.5, 0.3, (n, 1, 1))
+    tris = g.uniform(-1, 1, (n, 1, 3)) * scale + g.normal(0, 1, (n, 3, 3)) * size
+    if instanced:
+        # a mesh around its own origin, instanced a few times around `offset`
+        mesh = s.new_mesh()
+        s.add_triangles(tris.astype(np.float32) * 0.3, mats[int(g.integers(0, 3))], mesh=mesh)
+        if g.integers(0, 2):
+            s.add_sphere(tuple(g.uniform(-0.3, 0.3, 3) * scale), float(0.1 * scale), mats[int(g.integers(0, 3))], mesh=mesh)
+        if g.integers(0, 2):
+            lo = g.uniform(-0.3, 0.0, 3) * scale
+            s.add_cuboid(tuple(lo), tuple(lo + g.uniform(0.05, 0.3, 3) * scale), mats[0], mesh=mesh)
+        m = s.finish_mesh(mesh)
+        for _ in range(int(g.integers(1, 6))):
+            s.add_instance(m, float(g.uniform(-180, 180)), tuple(offset + g.uniform(-1, 1, 3) * scale))
+        s.add_triangles((tris[: max(1, n // 8)] + offset).astype(np.float32), mats[1])
+    else:
+        tris = (tris + offset).astype(np.float32)
+        cut = sorted(g.integers(0, n + 1, 2))
+        s.add_triangles(tris[: cut[0]], mats[0])
+        s.add_triangles(tris[cut[0]: cut[1]], mats[1])
+        s.add_triangles(tris[cut[1]:], mats[2])
+        for _ in range(int(g.integers(0, 4))):
+            s.add_sphere(tuple(offset + g.uniform(-1, 1, 3) * scale), float(scale * 10 ** g.uniform(-2, -0.3)), mats[int(g.integers(0, 4))])
+    light_c = offset + np.float32([0, 2.5 * scale, 0])
+    s.add_sphere(tuple(light_c), float(0.3 * scale), mats[3])
+    s.add_sphere_light(tuple(light_c), float(0.3 * scale))
+    s.background = (0.5, 0.6, 0.8)
+    s.camera = camera(rrt, np, g, offset, scale)
+    return s, n, scale
+
+
 def run(cases, seed, verbose=True):
     import numpy as np
     import rrt_pkg
@@ -31,41 +70,8 @@ def run(cases, seed, verbose=True):
     g = np.random.default_rng(seed)
     bad = 0
     for case in range(cases):
-        scale = 10 ** g.uniform(-2, 3)
-        offset = g.uniform(-1, 1, 3) * scale * 10 ** g.uniform(-1, 2)
-        s = rrt.Scene()
-        mats = [s.add_material(rrt.Lambertian(0.7, 0.6, 0.5)), s.add_material(rrt.Metal((0.8, 0.8, 0.9), 0.1)),
-                s.add_material(rrt.Dielectric(1.5)), s.add_material(rrt.DiffuseLight(3.0, 3.0, 3.0))]
         instanced = case % 3 == 2
-        n = int(10 ** g.uniform(1.3, 3.7 if instanced else 4.3))
-        size = scale * 10 ** g.uniform(-2.5, 0.3, (n, 1, 1))
-        tris = g.uniform(-1, 1, (n, 1, 3)) * scale + g.normal(0, 1, (n, 3, 3)) * size
-        if instanced:
-            # a mesh around its own origin, instanced a few times around `offset`
-            mesh = s.new_mesh()
-            s.add_triangles(tris.astype(np.float32) * 0.3, mats[int(g.integers(0, 3))], mesh=mesh)
-            if g.integers(0, 2):
-                s.add_sphere(tuple(g.uniform(-0.3, 0.3, 3) * scale), float(0.1 * scale), mats[int(g.integers(0, 3))], mesh=mesh)
-            if g.integers(0, 2):
-                lo = g.uniform(-0.3, 0.0, 3) * scale
-                s.add_cuboid(tuple(lo), tuple(lo + g.uniform(0.05, 0.3, 3) * scale), mats[0], mesh=mesh)
-            m = s.finish_mesh(mesh)
-            for _ in range(int(g.integers(1, 6))):
-                s.add_instance(m, float(g.uniform(-180, 180)), tuple(offset + g.uniform(-1, 1, 3) * scale))
-            s.add_triangles((tris[: max(1, n // 8)] + offset).astype(np.float32), mats[1])
-        else:
-            tris = (tris + offset).astype(np.float32)
-            cut = sorted(g.integers(0, n + 1, 2))
-            s.add_triangles(tris[: cut[0]], mats[0])
-            s.add_triangles(tris[cut[0]: cut[1]], mats[1])
-            s.add_triangles(tris[cut[1]:], mats[2])
-            for _ in range(int(g.integers(0, 4))):
-                s.add_sphere(tuple(offset + g.uniform(-1, 1, 3) * scale), float(scale * 10 ** g.uniform(-2, -0.3)), mats[int(g.integers(0, 4))])
-        light_c = offset + np.float32([0, 2.5 * scale, 0])
-        s.add_sphere(tuple(light_c), float(0.3 * scale), mats[3])
-        s.add_sphere_light(tuple(light_c), float(0.3 * scale))
-        s.background = (0.5, 0.6, 0.8)
-        s.camera = camera(rrt, np, g, offset, scale)
+        s, n, scale = random_scene(rrt, np, g, instanced)
         w, h = int(g.integers(1, 91)), int(g.integers(1, 91))
         spp, chunks = (12, 4) if g.integers(0, 2) else (37, 16)
         case_seed = int(g.integers(1, 1 << 30))
