@@ -4,7 +4,8 @@
 Flat scenes (triangle soups of very different sizes with spheres and rectangles): the convert and the scaled form of
 the box arithmetic, one item at a time and two in flight, whole tiles and items of a few pixels x many chunks.
 Instanced scenes (meshes of triangles, spheres and cuboids under Translate(RotateY)): the unrolled and the two-level
-form.  Cameras inside, touching and far away, fields of view of 0.5 .. 175 degrees."""
+form.  Every fifth scene: rrt_render_device_noalloc against rrt_render_device, and a group of two contexts against the
+sum of its two sample slices.  Cameras inside, touching and far away, fields of view of 0.5 .. 175 degrees."""
 import argparse
 import os
 import sys
@@ -89,6 +90,33 @@ def run(cases, seed, verbose=True):
                 bad += 1
                 print(f"MISMATCH case {case}: {knobs} instanced {instanced} n {n} scale {scale:.3g} {w}x{h} spp {spp} scaled_ok {info.scaled_slab}: rays {s0.rays} / {s1.rays}, "
                       f"{int((base != img).any(axis=-1).sum())} pixels differ", flush=True)
+        # every fifth scene: the entry point that allocates nothing, and a group of two contexts on this GPU whose
+        # members render half the samples each
+        if case % 5 == 0:
+            import helpers
+            r.set_tuning(overlap_items=None, split_items=None, scaled_slab=None, pixel_lists=None, chunks=None)
+            a, b = helpers.DeviceArray((h, w, 3)), helpers.DeviceArray((h, w, 3))
+            r.render_device(w, h, spp, 3, a.ptr, 0)
+            sa = r.render_stats()
+            r.render_device_noalloc(w, h, spp, 3, b.ptr, 0)
+            sb = r.render_stats()
+            if not (sa.rays == sb.rays and sa.chunks == sb.chunks and np.array_equal(a.numpy(), b.numpy())):
+                bad += 1
+                print(f"MISMATCH case {case}: render_device_noalloc against render_device, instanced {instanced} n {n} {w}x{h} spp {spp}: rays {sa.rays} / {sb.rays}", flush=True)
+            whole = a.numpy().copy()
+            a.free()
+            b.free()
+            if spp >= 2:
+                n_first = spp - spp // 2  # (the remainder of an uneven split goes to the first members)
+                first, s_first = r.render(w, h, n_first, spp_offset=3)
+                second, s_second = r.render(w, h, spp - n_first, spp_offset=3 + n_first)
+                grp = rrt.RendererGroup([0, 0], seed=case_seed)
+                grp.upload(s)
+                summed, s_group = grp.render(w, h, spp, spp_offset=3)
+                grp.close()
+                if not (s_group.rays == s_first.rays + s_second.rays == sa.rays and np.array_equal(summed, first + second)):
+                    bad += 1
+                    print(f"MISMATCH case {case}: group of two against the sum of its slices, instanced {instanced} n {n} {w}x{h} spp {spp}: rays {s_group.rays} / {s_first.rays + s_second.rays} / {sa.rays}", flush=True)
         r.close()
         if instanced:
             r2 = rrt.Renderer(seed=case_seed, unroll_instances=False)
