@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random scenes and ray batches: rrt_intersect (the BVH walk on the GPU) against the oracle's exhaustive search.
     python tools/stress_intersect.py [--cases 300] [--seed 1]      (on the GPU box)
-Flat and instanced scenes as in tools/stress_forms.py; per scene 4096 rays: camera rays, rays between random points
+Flat and instanced scenes as in tools/stress_forms.py, every fourth flat one large enough for the GPU's BVH builder and
+built by it; per scene 4096 rays: camera rays, rays between random points
 of the scene, axis-parallel rays, rays that start on a triangle.  Gate: primitive ids equal, t within 1e-5 relative.
 Prints every batch with differences and what kind they are (a hit the walk lacks / has in excess / another primitive)."""
 import argparse
@@ -30,7 +31,8 @@ def run(cases, seed, verbose=True):
         s = rrt.Scene()
         m0 = s.add_material(rrt.Lambertian(0.7, 0.6, 0.5))
         instanced = case % 3 == 2
-        n = int(10 ** g.uniform(1.0, 3.5))
+        device_build = not instanced and case % 4 == 0  # a tree the GPU builder makes (scenes of >= 4096 primitives)
+        n = int(10 ** g.uniform(3.7, 4.6)) if device_build else int(10 ** g.uniform(1.0, 3.5))
         size = scale * 10 ** g.uniform(-2.0, 0.3, (n, 1, 1))
         tris = g.uniform(-1, 1, (n, 1, 3)) * scale + g.normal(0, 1, (n, 3, 3)) * size
         if instanced:
@@ -74,8 +76,10 @@ def run(cases, seed, verbose=True):
         d = d * (10 ** g.uniform(-2, 2, (nr, 1)))
         rays["origin"], rays["direction"] = a.astype(np.float32), d.astype(np.float32)
         for unroll in ((True, False) if instanced else (True,)):
-            r = rrt.Renderer(unroll_instances=unroll)
-            r.upload(s)
+            r = rrt.Renderer(unroll_instances=unroll, device_build=device_build)
+            info = r.upload(s)
+            if device_build and not info.device_built:
+                print(f"NOTE case {case}: {n} triangles, and the upload fell back to the host builder", flush=True)
             got = r.intersect(rays)
             r.close()
             want = oracle.OracleScene(s).intersect(rays)
@@ -92,7 +96,7 @@ def run(cases, seed, verbose=True):
                 excess = int((wrong & ~hit).sum())
                 other = int(wrong.sum()) - lacks - excess
                 i = int(np.flatnonzero(wrong)[0])
-                print(f"DIFF case {case} (instanced {instanced}, unrolled {unroll}, n {n}, scale {scale:.3g}): {int(wrong.sum())} rays: walk lacks {lacks}, has in excess {excess}, "
+                print(f"DIFF case {case} (instanced {instanced}, unrolled {unroll}, device-built {device_build}, n {n}, scale {scale:.3g}): {int(wrong.sum())} rays: walk lacks {lacks}, has in excess {excess}, "
                       f"other primitive or t {other}; first: kind {int(kind[i])} got {got[i]} want {want[i]} |o-hit|/scale {float(want['t'][i]) * float(np.linalg.norm(d[i])) / scale:.3g}", flush=True)
         if verbose and case % 50 == 49:
             print(f"{case + 1} cases, {total} rays, {bad_cases} batches with differences, {bad_rays} rays", flush=True)
