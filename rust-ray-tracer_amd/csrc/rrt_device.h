@@ -852,7 +852,7 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, float x, float 
 // rays hits (a hit point lies inside its primitive's box, which the leaf's stored box contains with the builder's
 // margin to spare), so the closest hit of a primary ray of the pixel is the minimum over the primitive tests of the
 // leaves the pyramid touches -- the same minimum the ray's own walk forms, found without a walk.  The render kernel
-// collects those leaves once per work item and pixel (frustum_leaves) and resolves the pixel's primary rays against
+// collects them in a pass over the frame's pixels (k_pixel_lists) and resolves the pixel's primary rays against
 // the list (test_listed_leaf).  Scenes without instances only.
 // ---------------------------------------------------------------------------------------------
 struct PixelFrustum {
@@ -963,72 +963,16 @@ __device__ __forceinline__ float frustum_box_entry(const PixelFrustum& F, V3 mn,
     const float lo = ((x + y) + z) - 4e-6f * ((fabsf(x) + fabsf(y)) + fabsf(z));
     return fmaxf(lo * F.inv_amax, 0.0f) * 0.9999f;
 }
-// Collects the primitives a primary ray of the pixel can hit, as leaf references (a triangle as a triangle leaf of
-// one): the spheres and rectangles of the leaves of the scene's (one) BVH whose stored boxes the pyramid touches, and
-// those of their triangles that frustum_touches_triangle keeps; ordered by the lower bound of the ray parameter at
-// which a ray of the pixel can reach their leaf's box: refs[i], entry[i] for i < the returned count, or 0xFFFFFFFF
-// when there are more than `max_len` (<= KMAX; the pixel's primary rays then walk the tree like every other ray).
-// A plain depth-first walk on a private stack.
-template <int KMAX>
-__device__ __forceinline__ uint32_t frustum_leaves(const SceneDev& S, const PixelFrustum& F, uint32_t max_len, uint32_t* refs, float* entry) {
-    int todo[STACK_DEPTH];
-    float todo_t[STACK_DEPTH];
-    int sp = 0, cur = S.root;
-    float cur_t = 0.0f;
-    uint32_t n = 0u;
-    const V3 g0 = v3(S.grid.origin[0], S.grid.origin[1], S.grid.origin[2]), gs = v3(S.grid.step[0], S.grid.step[1], S.grid.step[2]);
-    for (;;) {
-        if (cur >= 0) {
-            const uint4* np = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
-            const uint4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
-            auto lo = [&](uint32_t wx, uint32_t wy, uint32_t wz) {
-                return v3(__builtin_fmaf((float)(wx & 0xFFFFu), gs.x, g0.x), __builtin_fmaf((float)(wy & 0xFFFFu), gs.y, g0.y), __builtin_fmaf((float)(wz & 0xFFFFu), gs.z, g0.z));
-            };
-            auto hi = [&](uint32_t wx, uint32_t wy, uint32_t wz) {
-                return v3(__builtin_fmaf((float)(wx >> 16), gs.x, g0.x), __builtin_fmaf((float)(wy >> 16), gs.y, g0.y), __builtin_fmaf((float)(wz >> 16), gs.z, g0.z));
-            };
-            const V3 lmn = lo(a.z, a.w, b.x), lmx = hi(a.z, a.w, b.x), rmn = lo(b.y, b.z, b.w), rmx = hi(b.y, b.z, b.w);
-            const bool hl = frustum_touches_box(F, lmn, lmx), hr = frustum_touches_box(F, rmn, rmx);
-            const float tl = frustum_box_entry(F, lmn, lmx), tr = frustum_box_entry(F, rmn, rmx);
-            if (hl && hr) {
-                if (sp == STACK_DEPTH) return 0xFFFFFFFFu;  // (deeper than any tree the builders make)
-                todo[sp] = (int)a.y; todo_t[sp] = tr; sp++;
-                cur = (int)a.x; cur_t = tl;
-                continue;
-            }
-            if (hl || hr) {
-                cur = hl ? (int)a.x : (int)a.y; cur_t = hl ? tl : tr;
-                continue;
-            }
-        } else {
-            const uint32_t kind = ((uint32_t)cur >> 28) & 7u;
-            // insertion by entry bound (lists are a handful of entries long)
-            auto insert = [&](uint32_t ref) {
-                uint32_t k = n;
-                while (k > 0u && entry[k - 1u] > cur_t) { refs[k] = refs[k - 1u]; entry[k] = entry[k - 1u]; --k; }
-                refs[k] = ref; entry[k] = cur_t;
-                n++;
-            };
-            if (kind == KIND_TRI) {
-                const uint32_t count = (((uint32_t)cur >> 25) & 7u) + 1u, first = (uint32_t)cur & REF_OFFSET_MASK;
-                for (uint32_t j = 0; j < count; ++j) {
-                    const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(S.tris) + (size_t)(first + j) * 48u);
-                    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-                    if (!frustum_touches_triangle(F, v3(q0.x, q0.y, q0.z), v3(q1.x, q1.y, q1.z), v3(q2.x, q2.y, q2.z))) continue;
-                    if (n == max_len) return 0xFFFFFFFFu;  // one more than a list may hold: no list, no point in going on
-                    insert((KIND_TRI << 28) | (first + j));
-                }
-            } else if (kind <= KIND_RECT) {  // a sphere, a rectangle (an empty child slot is skipped)
-                if (n == max_len) return 0xFFFFFFFFu;
-                insert((uint32_t)cur);
-            }
-        }
-        if (sp == 0) break;
-        --sp;
-        cur = todo[sp]; cur_t = todo_t[sp];
-    }
-    return n;
+// Inserts (ref, t) into the list refs[0 .. n), entry[0 .. n), which is ascending in entry (lists are a handful of
+// entries long).
+__device__ __forceinline__ void list_insert(uint32_t* refs, float* entry, uint32_t& n, uint32_t ref, float t) {
+    uint32_t k = n;
+    while (k > 0u && entry[k - 1u] > t) { refs[k] = refs[k - 1u]; entry[k] = entry[k - 1u]; --k; }
+    refs[k] = ref; entry[k] = t;
+    n++;
 }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const u32x4 const_u32x4;  // constant address space: a uniform address is fetched through the scalar cache
 // Tests the primitives of one listed leaf with the reference's arithmetic (what trav_leaf does for a walking lane).
 template <bool COUNT>
 __device__ __forceinline__ void test_listed_leaf(const SceneDev& S, uint32_t ref, V3 o, V3 d, float tmin, Best& best, TraceCounters& cnt) {

@@ -235,24 +235,110 @@ __global__ void k_add(float* __restrict__ dst, const float* __restrict__ src, si
     }
 }
 
-// The candidate leaves of every pixel's primary rays (rrt_device.h: frustum_leaves), one lane per pixel, written to
-// `lists` (PIXEL_LIST_DWORDS dwords per pixel, row-major).  Neighbouring pixels' pyramids walk the same nodes, so the
-// lanes of a wavefront (an 8x8 block of pixels) stay together.
+// The candidate lists of every pixel's primary rays, one lane per pixel, written to `lists` (PIXEL_LIST_DWORDS dwords
+// per pixel, row-major): per pixel the primitives a camera ray of the pixel can hit, as leaf references (a triangle as
+// a triangle leaf of one) -- the spheres and rectangles of the leaves whose stored boxes the pixel's pyramid touches,
+// and those of their triangles that frustum_touches_triangle keeps -- in ascending order of the lower bound of the ray
+// parameter at which a ray of the pixel can reach their leaf's box; 0xFFFFFFFF in place of the count when there are
+// more than max_len.
+// The 64 pixels of a wavefront (an 8x8 block) walk the tree TOGETHER: one depth-first walk over the nodes that any of
+// their pyramids touches, with one stack for the wavefront (a node reference and the mask of the lanes it concerns)
+// and every node and triangle record fetched once, through the scalar cache; a lane only tests what concerns it.
+// Neighbouring pyramids touch nearly the same nodes, so the shared walk is hardly longer than a single pixel's, and
+// it has no divergent control flow.  Leaves are handled where their parent is visited (the parent holds their box),
+// so the stack holds inner nodes only.
 // listed (one u64): the kernel adds the number of pixels that got a list.
-// (Five workgroups per CU: left to itself the kernel takes 141 registers and three wavefronts per SIMD, too few to
-// cover the walk's dependent fetches; at 102 registers it runs a fifth faster, at 64 it spills too much.)
-__global__ __launch_bounds__(256, 5) void k_pixel_lists(SceneDev S, uint32_t width, uint32_t height, uint32_t max_len, uint32_t* __restrict__ lists,
-                                                     unsigned long long* __restrict__ listed) {
+// (Six workgroups per CU, 80 registers; measured on MI355X at 4 / 5 / 6 / 7 / 8: 2.55 / 2.50 / 2.16 / 2.60 / 4.26 ms for
+// the 1M-triangle scene at 3840x2160.  One lane per pixel walking by itself took 3.3 ms.)
+__global__ __launch_bounds__(256, 6) void k_pixel_lists(SceneDev S, uint32_t width, uint32_t height, uint32_t max_len, uint32_t* __restrict__ lists,
+                                                        unsigned long long* __restrict__ listed) {
+    __shared__ int s_ref[4][STACK_DEPTH];
+    __shared__ unsigned long long s_mask[4][STACK_DEPTH];
     const uint32_t tiles_x = (width + 7u) / 8u;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t wv = threadIdx.x >> 6, wave = blockIdx.x * 4u + wv, lane = threadIdx.x & 63u;
     const uint32_t x = (wave % tiles_x) * 8u + (lane & 7u), y = (wave / tiles_x) * 8u + (lane >> 3);
     const bool inside = x < width && y < height;
+    const PixelFrustum F = pixel_frustum(S.cam, min(x, width - 1u), min(y, height - 1u), width, height);
     uint32_t refs[PIXEL_LIST_MAX];
     float entry[PIXEL_LIST_MAX];
-    uint32_t n = 0xFFFFFFFFu;
-    if (inside) {
-        const PixelFrustum F = pixel_frustum(S.cam, x, y, width, height);
-        if (F.ok) n = frustum_leaves<(int)PIXEL_LIST_MAX>(S, F, max_len, refs, entry);
+    uint32_t n = inside && F.ok ? 0u : 0xFFFFFFFFu;
+    const V3 g0 = v3(S.grid.origin[0], S.grid.origin[1], S.grid.origin[2]), gs = v3(S.grid.step[0], S.grid.step[1], S.grid.step[2]);
+    // A leaf child of the node being visited, for the lanes in `mine`: its candidates go into their lists.
+    auto take_leaf = [&](uint32_t leaf, bool mine, float leaf_t) {
+        const uint32_t kind = (leaf >> 28) & 7u;
+        if (kind == KIND_TRI) {
+            const uint32_t count = ((leaf >> 25) & 7u) + 1u, first = leaf & REF_OFFSET_MASK;
+            for (uint32_t j = 0; j < count; ++j) {
+                const const_u32x4* rec = (const const_u32x4*)(reinterpret_cast<const char*>(S.tris) + (size_t)(first + j) * 48u);
+                const u32x4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+                if (mine && n != 0xFFFFFFFFu &&
+                    frustum_touches_triangle(F, v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
+                                             v3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
+                                             v3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)))) {
+                    if (n == max_len) n = 0xFFFFFFFFu;  // one more than a list may hold: no list
+                    else list_insert(refs, entry, n, (KIND_TRI << 28) | (first + j), leaf_t);
+                }
+            }
+        } else if (kind <= KIND_RECT) {  // a sphere, a rectangle (an empty child slot is skipped)
+            if (mine && n != 0xFFFFFFFFu) {
+                if (n == max_len) n = 0xFFFFFFFFu;
+                else list_insert(refs, entry, n, leaf, leaf_t);
+            }
+        }
+    };
+    int cur = S.root;  // uniform
+    unsigned long long cur_mask = __ballot(n != 0xFFFFFFFFu);
+    int sp = 0;
+    if (cur < 0) {  // a scene of one leaf
+        take_leaf((uint32_t)cur, n != 0xFFFFFFFFu, 0.0f);
+        cur_mask = 0ull;
+    }
+    while (cur_mask != 0ull) {
+        const const_u32x4* np = (const const_u32x4*)(reinterpret_cast<const char*>(S.nodes) + (uint32_t)cur);
+        const u32x4 a = np[0], b = np[1];  // a = (left, right, L.x, L.y)  b = (L.z, R.x, R.y, R.z)
+        const bool mine = ((cur_mask >> lane) & 1ull) != 0ull && n != 0xFFFFFFFFu;
+        auto lo = [&](uint32_t wx, uint32_t wy, uint32_t wz) {
+            return v3(__builtin_fmaf((float)(wx & 0xFFFFu), gs.x, g0.x), __builtin_fmaf((float)(wy & 0xFFFFu), gs.y, g0.y), __builtin_fmaf((float)(wz & 0xFFFFu), gs.z, g0.z));
+        };
+        auto hi = [&](uint32_t wx, uint32_t wy, uint32_t wz) {
+            return v3(__builtin_fmaf((float)(wx >> 16), gs.x, g0.x), __builtin_fmaf((float)(wy >> 16), gs.y, g0.y), __builtin_fmaf((float)(wz >> 16), gs.z, g0.z));
+        };
+        const V3 lmn = lo(a.z, a.w, b.x), lmx = hi(a.z, a.w, b.x), rmn = lo(b.y, b.z, b.w), rmx = hi(b.y, b.z, b.w);
+        const bool hl = mine && frustum_touches_box(F, lmn, lmx), hr = mine && frustum_touches_box(F, rmn, rmx);
+        unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+        const int left = (int)a.x, right = (int)a.y;
+        if (left < 0) {
+            if (ml != 0ull) take_leaf((uint32_t)left, hl, hl ? frustum_box_entry(F, lmn, lmx) : 0.0f);
+            ml = 0ull;
+        }
+        if (right < 0) {
+            if (mr != 0ull) take_leaf((uint32_t)right, hr, hr ? frustum_box_entry(F, rmn, rmx) : 0.0f);
+            mr = 0ull;
+        }
+        if (ml != 0ull && mr != 0ull) {
+            if (sp == STACK_DEPTH) {  // (deeper than any tree the builders make: nobody gets a list)
+                n = 0xFFFFFFFFu;
+                break;
+            }
+            if (lane == 0u) { s_ref[wv][sp] = right; s_mask[wv][sp] = mr; }
+            sp++;
+            cur = left; cur_mask = ml;
+        } else if (ml != 0ull) {
+            cur = left; cur_mask = ml;
+        } else if (mr != 0ull) {
+            cur = right; cur_mask = mr;
+        } else {
+            // the next node on the stack that still concerns a lane with a list
+            cur_mask = 0ull;
+            const unsigned long long alive = __ballot(n != 0xFFFFFFFFu);
+            while (sp > 0 && cur_mask == 0ull) {
+                --sp;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                cur = __builtin_amdgcn_readfirstlane(s_ref[wv][sp]);
+                const unsigned long long m = s_mask[wv][sp];
+                cur_mask = (((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(m >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)m)) & alive;
+            }
+        }
     }
     const unsigned long long got = __ballot(inside && n != 0xFFFFFFFFu);
     if (lane == 0u && got != 0ull) atomicAdd(listed, (unsigned long long)__popcll(got));
