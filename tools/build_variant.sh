@@ -9,7 +9,7 @@ NAME=$1; shift
 mkdir -p exp_libs
 BASE="--offload-arch=gfx950 ${OPT:--O3} -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -fno-slp-vectorize"
 if [ -z "$UNROLLED_ONLY" ]; then
-    /opt/rocm/bin/hipcc $BASE -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c csrc/rrt_kernels.hip -o exp_libs/$NAME.o
+    /opt/rocm/bin/hipcc $BASE -mllvm -amdgpu-sched-strategy=${SCHED:-iterative-ilp} "$@" -c csrc/rrt_kernels.hip -o exp_libs/$NAME.o
     K1=exp_libs/$NAME.o
 else
     K1=csrc/rrt_kernels.o
