@@ -219,10 +219,15 @@ def main():
     kernel_ms = []
     rays_per_step = 0
 
+    last_note = [time.perf_counter()]
+
     def step(record: bool):
         nonlocal rays_per_step
         renderer.render_device(width, height, spp, spp_offset, accum.data_ptr(), stream.cuda_stream)
         st = renderer.render_stats()  # waits for the kernel; its HIP events are on `stream`
+        if rank == 0 and time.perf_counter() - last_note[0] > 30.0:  # (long frames: a sign of life on stderr)
+            last_note[0] = time.perf_counter()
+            print(f"bench.py: a step of {st.kernel_ms:.0f} ms done", file=sys.stderr, flush=True)
         rdist.reduce_accum(accum, dst=0, via_host=rehearsal)
         if rank == 0:
             renderer.tonemap_device(accum.data_ptr(), width, height, spp_total, rgb8.data_ptr(), stream.cuda_stream)
