@@ -577,27 +577,36 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // Scenes with a real hierarchy (>= 4096 nodes): paths bounce and walks are long, so items of 8 samples, the
     // straggler rule and lanes that move on to the next item by themselves pay; on tiny scenes each of them costs.
     const bool big_scene = c->info.node_count >= 4096u;
-    // Multi-million-node scenes (fetch-bound: more than the caches hold) keep items of 64 pixels x one chunk and get
-    // larger chunks on large frames (measured on the unrolled 10M-triangle scene at 8K: 256 spp in 8 / 16 / 32 chunks
-    // 2350 / 2385 / 2478 ms; items of a few pixels x many chunks: 2376 ms, and 165.7 against 160.0 ms at 16 spp); other
-    // large scenes get chunks of 8 samples, which their items hold side by side (launch_render).
+    // Multi-million-node scenes (fetch-bound: more than the caches hold): instanced ones, and short frames, keep items
+    // of 64 pixels x one chunk and get larger chunks on large frames (measured on the unrolled 10M-triangle scene at 8K:
+    // 256 spp in 8 / 16 / 32 chunks 2350 / 2385 / 2478 ms; items of a few pixels x many chunks: 2376 ms, and 165.7 against
+    // 160.0 ms at 16 spp); other large scenes get chunks of 8 samples, which their items hold side by side
+    // (launch_render).
     const bool huge_scene = c->info.node_count >= (1u << 21);
+    const bool flat_scene = c->sdev.unroll_shift == 0u && c->sdev.has_instances == 0u;
+    const bool one_tree = c->sdev.unroll_shift != 0u || c->sdev.has_instances == 0u;  // no instances, or all of them unrolled
     const uint64_t pixels = (uint64_t)width * height;
     uint32_t per_item = 8u;
     if (huge_scene && spp >= 64u && pixels >= 6000000ull) per_item = 16u;
     if (huge_scene && spp >= 128u && pixels >= 24000000ull) per_item = 32u;
+    // A multi-million-node scene walked as one tree (no instances, or unrolled ones), from 128 samples on: items of 8
+    // pixels x 8 long chunks whose primary rays take per-pixel candidate lists (below).  Measured on MI355X, 10M unique triangles at 8K, whole tiles against
+    // this form: 64 spp 606.5 / 600.6 ms, 128 spp 1193.0 / 1122.4, 256 spp 2364.1 / 2025.0 (16 / 32 chunks: 2154.6 /
+    // 2228.3; 8 chunks without lists: 2322.2), 512 spp 4720.6 / 3940.1 (16 / 32 chunks: 4145.6 / 3940.5), 1024 spp
+    // 9368.7 / 7778.6 (16 / 32 chunks: 8108.9 / 8081.2).
+    const bool huge_lists = huge_scene && one_tree && tn.pixel_lists != 0u && spp >= 128u;
     // Items of a few pixels x many of their chunks (launch_render) on every other scene without instances that has
     // pixels of unequal cost to even out: suzanne 1080p x 256 spp 11.1 -> 10.6 ms, x 1024 spp 32.7 -> 29.9 ms; not on
     // scenes of a few primitives (12-primitive scene 0.94 -> 1.03 ms with it).
-    bool split_items = tn.split_items != RRT_TUNE_AUTO ? tn.split_items != 0u : (!huge_scene && c->info.node_count >= 64u);
+    bool split_items = tn.split_items != RRT_TUNE_AUTO ? tn.split_items != 0u : ((!huge_scene || huge_lists) && c->info.node_count >= 64u);
     // Frames whose primary rays can take per-pixel candidate lists (below; whether a launch collects them also depends on
     // what the last one found, which must not change how a frame is cut): a listed sample costs one trip less, so an
     // item holds 16 samples per lane for its 16 trips (measured on MI355X, 1M-triangle scene at 4K with lists: 128 spp in
     // 8 / 16 / 32 chunks 118.7 / 120.3 / 132.5 ms, 256 spp 223.2 / 220.1 / 231.3 ms, 100 spp 95.6 / 99.3 / 112.7 ms).
-    const bool lists_possible = tn.pixel_lists != 0u && spp >= 32u && split_items && !huge_scene &&
-                                c->sdev.unroll_shift == 0u && c->sdev.has_instances == 0u;
+    const bool lists_possible = tn.pixel_lists != 0u && spp >= 32u && split_items && (huge_scene ? huge_lists : flat_scene);
     if (lists_possible && big_scene) per_item = 16u;
     uint32_t n_chunks = render_chunks(width, height, spp, big_scene ? per_item : 16u);
+    if (lists_possible && huge_scene) n_chunks = 8u;
     if (tn.chunks != RRT_TUNE_AUTO) n_chunks = std::min(tn.chunks, spp);
     while (n_chunks > 1u && (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * n_chunks > 0x7FFFFFFFull) n_chunks /= 2u;
     // Split items hold a power of two of chunks side by side (launch_render): the power of two from 8 to 32 nearest (in

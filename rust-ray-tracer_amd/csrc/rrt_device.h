@@ -853,7 +853,8 @@ __device__ __forceinline__ void camera_ray(const CameraRec& cam, float x, float 
 // margin to spare), so the closest hit of a primary ray of the pixel is the minimum over the primitive tests of the
 // leaves the pyramid touches -- the same minimum the ray's own walk forms, found without a walk.  The render kernel
 // collects them in a pass over the frame's pixels (k_pixel_lists) and resolves the pixel's primary rays against
-// the list (test_listed_leaf).  Scenes without instances only.
+// the list (test_listed_leaf).  Scenes without instances, and scenes whose instances are unrolled into one world-space
+// tree (the boxes are world boxes there too; a triangle of an instance is moved to world space for the pyramid's tests).
 // ---------------------------------------------------------------------------------------------
 struct PixelFrustum {
     V3 o;
@@ -864,7 +865,9 @@ struct PixelFrustum {
     float d_l1;     // the largest 1-norm of a corner ray
     bool ok;        // false: the camera arithmetic is too coarse for a pyramid of this pixel to mean anything (no list)
 };
-__device__ __forceinline__ PixelFrustum pixel_frustum(const CameraRec& cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
+// err_scale: 1 for rays that are tested as the camera forms them; 3 where a ray is also moved into an instance's space
+// before a test (Translate::hit, RotateY::hit: two more roundings of its origin and direction at the same magnitudes).
+__device__ __forceinline__ PixelFrustum pixel_frustum(const CameraRec& cam, uint32_t px, uint32_t py, uint32_t w, uint32_t h, float err_scale = 1.0f) {
     // The jittered coordinates of the pixel lie in [px, px + 1] x [py, py + 1].  Slack on every side: 1/64 of a pixel,
     // plus what the rounding of camera_ray can move a ray (and the corner rays formed here) across the image plane:
     // ray_p is rounded at the magnitude of the camera's position, however short the camera's axes are, i.e. each of
@@ -872,7 +875,7 @@ __device__ __forceinline__ PixelFrustum pixel_frustum(const CameraRec& cam, uint
     // axes, is a shift of the ray's image-plane coordinates (its part along the view axis rescales them).
     const V3 q0 = v3(cam.c0[0], cam.c0[1], cam.c0[2]), q1 = v3(cam.c1[0], cam.c1[1], cam.c1[2]), q2 = v3(cam.c2[0], cam.c2[1], cam.c2[2]);
     const float ax = fabsf(cam.scale * cam.aspect), ay = fabsf(cam.scale);
-    const float err = 2.5e-7f * fmaxf(fmaxf(fabsf(cam.tr[0]) + fabsf(q0.x) * ax + fabsf(q1.x) * ay + fabsf(q2.x),
+    const float err = err_scale * 2.5e-7f * fmaxf(fmaxf(fabsf(cam.tr[0]) + fabsf(q0.x) * ax + fabsf(q1.x) * ay + fabsf(q2.x),
                                             fabsf(cam.tr[1]) + fabsf(q0.y) * ax + fabsf(q1.y) * ay + fabsf(q2.y)),
                                       fabsf(cam.tr[2]) + fabsf(q0.z) * ax + fabsf(q1.z) * ay + fabsf(q2.z));
     const V3 r0 = cross(q1, q2), r1 = cross(q2, q0), r2 = cross(q0, q1);  // rows of the inverse of (q0 q1 q2), times its determinant
@@ -908,14 +911,15 @@ __device__ __forceinline__ PixelFrustum pixel_frustum(const CameraRec& cam, uint
 //     so it then lies outside the pyramid by that much.  rho covers what test_triangle's own rounding can add to a
 //     triangle's extent: its barycentric coordinates carry an error of a few ulps of |o - v0| / |e|, i.e. it accepts
 //     rays that pass the triangle at a few ulps of the distance to it.
-// Both with allowances of tens of ulps of the sums' terms.
-__device__ __forceinline__ bool frustum_touches_triangle(const PixelFrustum& F, V3 v0, V3 e1, V3 e2) {
+// Both with allowances of tens of ulps of the sums' terms (times `slack`: 2 for a triangle of an instance, whose corners
+// the caller has moved to world space and whose test runs on the ray moved the other way).
+__device__ __forceinline__ bool frustum_touches_triangle(const PixelFrustum& F, V3 v0, V3 e1, V3 e2, float slack = 1.0f) {
     const V3 m = cross(e2, e1);
     const float det_max = fmaxf(fmaxf(dot(F.d[0], m), dot(F.d[1], m)), fmaxf(dot(F.d[2], m), dot(F.d[3], m)));
     const float le1 = norm1(e1), le2 = norm1(e2);
-    if (det_max < -4e-6f * (le1 * le2 * F.d_l1)) return false;
+    if (det_max < -4e-6f * slack * (le1 * le2 * F.d_l1)) return false;
     const V3 p0 = v0 - F.o, p1 = p0 + e1, p2 = p0 + e2;
-    const float rho = 4e-6f * ((norm1(p0) + le1) + le2);
+    const float rho = 4e-6f * slack * ((norm1(p0) + le1) + le2);
     bool in = true;
     for (int k = 0; k < 4; ++k) {
         const V3 n = F.n[k];
@@ -934,7 +938,7 @@ __device__ __forceinline__ bool frustum_touches_triangle(const PixelFrustum& F, 
     const float vol = dot(m01, p2);  // the same triple product for all three edges (cyclic order)
     if (!(fabsf(vol) > 1e-5f * (norm1(m01) * norm1(p2)))) return true;  // seen edge-on: kept
     const float sgn = vol > 0.0f ? 1.0f : -1.0f;
-    const float per_norm = rho * __builtin_amdgcn_rcpf(z_min * F.inv_amax) * 1.0001f + 2e-6f * F.d_l1;
+    const float per_norm = rho * __builtin_amdgcn_rcpf(z_min * F.inv_amax) * 1.0001f + 2e-6f * slack * F.d_l1;
     auto outside = [&](V3 m) {
         const float inmost = fmaxf(fmaxf(sgn * dot(m, F.d[0]), sgn * dot(m, F.d[1])), fmaxf(sgn * dot(m, F.d[2]), sgn * dot(m, F.d[3])));
         return inmost < -per_norm * norm1(m);
@@ -974,20 +978,44 @@ __device__ __forceinline__ void list_insert(uint32_t* refs, float* entry, uint32
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const u32x4 const_u32x4;  // constant address space: a uniform address is fetched through the scalar cache
 // Tests the primitives of one listed leaf with the reference's arithmetic (what trav_leaf does for a walking lane).
-template <bool COUNT>
-__device__ __forceinline__ void test_listed_leaf(const SceneDev& S, uint32_t ref, V3 o, V3 d, float tmin, Best& best, TraceCounters& cnt) {
-    const uint32_t kind = (ref >> 28) & 7u, first = ref & REF_OFFSET_MASK;
+// MODE_UNROLLED: the reference names its instance slot above the record index; the ray goes into that instance's
+// space for the test as in trav_leaf (xf_lds: the workgroup's LDS copy of the transforms, or nullptr).
+template <bool COUNT, int MODE = MODE_FLAT>
+__device__ __forceinline__ void test_listed_leaf(const SceneDev& S, uint32_t ref, V3 o, V3 d, float tmin, Best& best, TraceCounters& cnt,
+                                                 const lds_float4* xf_lds = nullptr) {
+    const uint32_t kind = (ref >> 28) & 7u;
+    uint32_t first = ref & REF_OFFSET_MASK;
+    int32_t inst = -1;
+    if (MODE == MODE_UNROLLED) {
+        inst = (int32_t)(first >> S.unroll_shift) - 1;
+        first &= (1u << S.unroll_shift) - 1u;
+        if (inst >= 0) {
+            float4 x0, x1;
+            if (xf_lds != nullptr) {
+                const lds_float4* e = xf_lds + 2 * (inst + 1);
+                const vec4f e0 = e[0], e1 = e[1];
+                x0 = make_float4(e0.x, e0.y, e0.z, e0.w);
+                x1 = make_float4(e1.x, e1.y, e1.z, e1.w);
+            } else {
+                x0 = reinterpret_cast<const float4*>(&S.insts[inst])[0];
+                x1 = reinterpret_cast<const float4*>(&S.insts[inst])[1];
+            }
+            const V3 m = o - v3(x0.x, x0.y, x0.z);  // Translate::hit, RotateY::hit (transform.rs:24,101-108), as trav_leaf forms them
+            o = v3(x1.y * m.x - x1.x * m.z, m.y, x1.x * m.x + x1.y * m.z);
+            d = v3(x1.y * d.x - x1.x * d.z, d.y, x1.x * d.x + x1.y * d.z);
+        }
+    }
     if (kind == KIND_TRI) {
         const uint32_t count = ((ref >> 25) & 7u) + 1u;
         for (uint32_t j = 0; j < count; ++j) {
-            test_triangle(S, first + j, o, d, tmin, -1, best);
+            test_triangle(S, first + j, o, d, tmin, inst, best);
             if (COUNT) cnt.prims++;
         }
     } else if (kind == KIND_SPHERE) {
-        test_sphere(S, first, o, d, tmin, -1, best);
+        test_sphere(S, first, o, d, tmin, inst, best);
         if (COUNT) cnt.prims++;
     } else {
-        test_rect(S, first, o, d, tmin, -1, best);
+        test_rect(S, first, o, d, tmin, inst, best);
         if (COUNT) cnt.prims++;
     }
 }

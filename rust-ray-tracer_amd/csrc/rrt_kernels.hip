@@ -250,6 +250,10 @@ __global__ void k_add(float* __restrict__ dst, const float* __restrict__ src, si
 // listed (one u64): the kernel adds the number of pixels that got a list.
 // (Six workgroups per CU, 80 registers; measured on MI355X at 4 / 5 / 6 / 7 / 8: 2.55 / 2.50 / 2.16 / 2.60 / 4.26 ms for
 // the 1M-triangle scene at 3840x2160.  One lane per pixel walking by itself took 3.3 ms.)
+// UNROLLED: a leaf's reference names its instance slot above the record index (SceneDev::unroll_shift); the records of
+// an instance's triangles are in the mesh's space and are moved to world space (the point map of transform.rs:113-124
+// and 27) before the pyramid's tests; entries keep the slot, so that the render kernel tests them as its walk would.
+template <bool UNROLLED>
 __global__ __launch_bounds__(256, 6) void k_pixel_lists(SceneDev S, uint32_t width, uint32_t height, uint32_t max_len, uint32_t* __restrict__ lists,
                                                         unsigned long long* __restrict__ listed) {
     __shared__ int s_ref[4][STACK_DEPTH];
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256, 6) void k_pixel_lists(SceneDev S, uint32_t wid
     const uint32_t wv = threadIdx.x >> 6, wave = blockIdx.x * 4u + wv, lane = threadIdx.x & 63u;
     const uint32_t x = (wave % tiles_x) * 8u + (lane & 7u), y = (wave / tiles_x) * 8u + (lane >> 3);
     const bool inside = x < width && y < height;
-    const PixelFrustum F = pixel_frustum(S.cam, min(x, width - 1u), min(y, height - 1u), width, height);
+    const PixelFrustum F = pixel_frustum(S.cam, min(x, width - 1u), min(y, height - 1u), width, height, UNROLLED ? 3.0f : 1.0f);
     uint32_t refs[PIXEL_LIST_MAX];
     float entry[PIXEL_LIST_MAX];
     uint32_t n = inside && F.ok ? 0u : 0xFFFFFFFFu;
@@ -268,13 +272,32 @@ __global__ __launch_bounds__(256, 6) void k_pixel_lists(SceneDev S, uint32_t wid
         const uint32_t kind = (leaf >> 28) & 7u;
         if (kind == KIND_TRI) {
             const uint32_t count = ((leaf >> 25) & 7u) + 1u, first = leaf & REF_OFFSET_MASK;
+            uint32_t rec0 = first;
+            float sn = 0.0f, cs = 1.0f, slack = 1.0f;
+            V3 off = v3(0.0f, 0.0f, 0.0f);
+            if (UNROLLED) {
+                rec0 = first & ((1u << S.unroll_shift) - 1u);
+                const uint32_t slot = first >> S.unroll_shift;  // uniform, like the leaf
+                if (slot != 0u) {
+                    const const_u32x4* ir = (const const_u32x4*)(S.insts + (slot - 1u));
+                    const u32x4 x0 = ir[0], x1 = ir[1];
+                    off = v3(__uint_as_float(x0.x), __uint_as_float(x0.y), __uint_as_float(x0.z));
+                    sn = __uint_as_float(x1.x); cs = __uint_as_float(x1.y);
+                    slack = 2.0f;
+                }
+            }
             for (uint32_t j = 0; j < count; ++j) {
-                const const_u32x4* rec = (const const_u32x4*)(reinterpret_cast<const char*>(S.tris) + (size_t)(first + j) * 48u);
+                const const_u32x4* rec = (const const_u32x4*)(reinterpret_cast<const char*>(S.tris) + (size_t)(rec0 + j) * 48u);
                 const u32x4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-                if (mine && n != 0xFFFFFFFFu &&
-                    frustum_touches_triangle(F, v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
-                                             v3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z)),
-                                             v3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z)))) {
+                V3 v0 = v3(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+                V3 e1 = v3(__uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z));
+                V3 e2 = v3(__uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z));
+                if (UNROLLED) {
+                    v0 = v3(cs * v0.x + sn * v0.z, v0.y, -sn * v0.x + cs * v0.z) + off;
+                    e1 = v3(cs * e1.x + sn * e1.z, e1.y, -sn * e1.x + cs * e1.z);
+                    e2 = v3(cs * e2.x + sn * e2.z, e2.y, -sn * e2.x + cs * e2.z);
+                }
+                if (mine && n != 0xFFFFFFFFu && frustum_touches_triangle(F, v0, e1, e2, slack)) {
                     if (n == max_len) n = 0xFFFFFFFFu;  // one more than a list may hold: no list
                     else list_insert(refs, entry, n, (KIND_TRI << 28) | (first + j), leaf_t);
                 }
@@ -374,7 +397,9 @@ uint32_t render_chunks(uint32_t width, uint32_t height, uint32_t spp, uint32_t s
 
 bool render_takes_pixel_lists(const SceneDev& S, uint32_t width, uint32_t height, uint32_t n_chunks, const RenderTuning& tuning) {
     if (tuning.pixel_lists == 0u || tuning.split_items == 0u || width >= 65536u || height >= 65536u) return false;
-    if (S.unroll_shift != 0u || S.has_instances != 0u || n_chunks < 64u / (uint32_t)LIST_PIXELS) return false;
+    // (a scene whose instances are unrolled is walked as one world-space tree like a scene without instances; a
+    // two-level scene's instance leaves hold whole meshes)
+    if ((S.unroll_shift == 0u && S.has_instances != 0u) || n_chunks < 64u / (uint32_t)LIST_PIXELS) return false;
     return true;
 }
 
@@ -394,7 +419,9 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     if (n_chunks == 0u || n_chunks > spp) return hipErrorInvalidValue;  // every chunk holds at least one sample
     uint32_t pix_log2 = 6u;
     const int mode = S.unroll_shift != 0u ? MODE_UNROLLED : (S.has_instances != 0u ? MODE_TWO_LEVEL : MODE_FLAT);
-    if (tuning.split_items != 0u && mode == MODE_FLAT) {
+    // (unrolled scenes are only built with split items together with lists)
+    const bool lists_wanted = d_lists != nullptr && render_takes_pixel_lists(S, width, height, n_chunks, tuning);
+    if (tuning.split_items != 0u && (mode == MODE_FLAT || (mode == MODE_UNROLLED && lists_wanted))) {
 #ifdef RRT_PIPE_PIX_LOG2
         pix_log2 = RRT_PIPE_PIX_LOG2;
 #else
@@ -407,6 +434,7 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
         const uint64_t items = (uint64_t)((width + (1u << w_log2) - 1u) >> w_log2) * ((height + (1u << h_log2) - 1u) >> h_log2) *
                                ((n_chunks + (64u >> pix_log2) - 1u) >> (6u - pix_log2));
         if (items > 0x7FFFFFFFull) pix_log2 = 6u;
+        if (mode == MODE_UNROLLED && (1u << pix_log2) > (uint32_t)LIST_PIXELS) pix_log2 = 6u;
     }
     const uint32_t tw_log2 = pix_log2 == 6u ? (uint32_t)RRT_TILE_W_LOG2 : pix_log2 / 2u;
     const uint32_t tw = 1u << tw_log2, th = (1u << pix_log2) / tw, sub = 64u >> pix_log2;
@@ -435,16 +463,23 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
     // the scaled slab arithmetic where the host found it valid for this scene (S.sigma != 0) and the walk stays on one grid
     const bool scaled = S.sigma != 0.0f && tuning.scaled_slab != 0u && mode != MODE_TWO_LEVEL;
     const unsigned variant = (scaled ? 16u : 0u) | ((unsigned)mode << 2) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u);
-    if (mode == MODE_UNROLLED) {
-        e = launch_render_unrolled(count_visits, pipelined, scaled, S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream);
-    } else if (pix_log2 != 6u && d_lists != nullptr && render_takes_pixel_lists(S, width, height, n_chunks, tuning) && (1u << pix_log2) <= (uint32_t)LIST_PIXELS) {
+    const bool lists = pix_log2 != 6u && lists_wanted && (1u << pix_log2) <= (uint32_t)LIST_PIXELS;
+    if (lists) {
         // split items of a few pixels: primary rays resolved against per-pixel candidate lists, which a pass over the
         // frame's pixels collects first
         const uint32_t waves = ((width + 7u) / 8u) * ((height + 7u) / 8u);
-        hipLaunchKernelGGL(k_pixel_lists, dim3((waves + 3u) / 4u), dim3(256), 0, stream, S, width, height,
-                           std::min(tuning.pixel_list_len, PIXEL_LIST_MAX), d_lists, d_counters + 14);
+        const uint32_t max_len = std::min(tuning.pixel_list_len, PIXEL_LIST_MAX);
+        if (mode == MODE_UNROLLED)
+            hipLaunchKernelGGL(k_pixel_lists<true>, dim3((waves + 3u) / 4u), dim3(256), 0, stream, S, width, height, max_len, d_lists, d_counters + 14);
+        else
+            hipLaunchKernelGGL(k_pixel_lists<false>, dim3((waves + 3u) / 4u), dim3(256), 0, stream, S, width, height, max_len, d_lists, d_counters + 14);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         G.lists = d_lists;
+    }
+    if (mode == MODE_UNROLLED) {
+        e = lists ? launch_render_unrolled_lists(count_visits, pipelined, scaled, S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream)
+                  : launch_render_unrolled(count_visits, pipelined, scaled, S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream);
+    } else if (lists) {
         const bool roomy = pipelined && tuning.list_waves == 6u;
         switch ((roomy ? 8u : 0u) | (scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {
             case 15u: e = launch_render_variant<MODE_FLAT, true, true, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;

@@ -107,6 +107,15 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_ONE_LIST_ROUNDS
 #define RRT_ONE_LIST_ROUNDS 2  // one-item form with pixel lists: rounds of a shade phase (the new samples of all but the last take their lists)
 #endif
+#ifndef RRT_UL_STACK_CUT
+#define RRT_UL_STACK_CUT 4  // unrolled scenes with lists: entries of the traversal stack moved from LDS to private memory
+#endif
+#ifndef RRT_UL_WAVES
+#define RRT_UL_WAVES RRT_UNROLLED_WAVES  // unrolled scenes with lists: workgroups per CU the pipelined form is compiled for
+#endif
+#ifndef RRT_UL_XF
+#define RRT_UL_XF 1  // unrolled scenes with lists: 1 = the table of instance transforms is copied to LDS
+#endif
 #ifndef RRT_ONE_ITEM_WAVES
 #define RRT_ONE_ITEM_WAVES 6  // workgroups per CU the one-item form (small scenes) is compiled for
 #endif
@@ -115,7 +124,7 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 // SPLIT (scenes without instances): an item's 64 lanes are 2^G.pix_log2 pixels times several of their
 // sample chunks instead of 64 pixels times one (launch_render picks the split); a template parameter because the
 // general index arithmetic costs the other scenes 1-3 % when it is merely switched off at run time.
-// LISTS (split items of at most LIST_PIXELS pixels, scenes without instances): a kernel run before this one
+// LISTS (split items of at most LIST_PIXELS pixels, scenes walked as one world-space tree): a kernel run before this one
 // (k_pixel_lists) has collected, for every pixel, the primitives a camera ray of the pixel can hit.  When a
 // wavefront draws an item it copies the lists of the item's pixels to LDS; a lane that starts a sample of a pixel with a
 // list resolves its primary ray against that list inside the shading phase -- a couple of primitive tests instead of a
@@ -127,26 +136,28 @@ static constexpr int LIST_PIXELS = 8;   // pixels of an item that get a list
 // depends on the scene (measured on MI355X: the 1M-triangle scene 764 -> 740 ms with six, MetalRoughSpheres 258 -> 262):
 // the caller chooses (RenderTuning::list_waves).
 template <int MODE, bool COUNT, bool PIPELINED, bool SCALED, bool SPLIT = false, bool LISTS = false, bool ROOMY = false>
-__global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? RRT_UNROLLED_WAVES : (ROOMY ? RRT_FLAT_WAVES - 1 : RRT_FLAT_WAVES)) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
+__global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAVES : (PIPELINED ? (MODE == MODE_UNROLLED ? (LISTS ? RRT_UL_WAVES : RRT_UNROLLED_WAVES) : (ROOMY ? RRT_FLAT_WAVES - 1 : RRT_FLAT_WAVES)) : RRT_ONE_ITEM_WAVES)) void k_render(SceneDev S, RenderGeom G, float* __restrict__ out,
                                                          unsigned long long* __restrict__ counters,
                                                          unsigned int* __restrict__ heads) {
     constexpr bool INST = MODE == MODE_TWO_LEVEL;
     static_assert(!(SCALED && INST), "the scaled slab arithmetic is for scenes walked on one grid");
-    static_assert(!LISTS || (SPLIT && MODE == MODE_FLAT), "pixel lists: split items, no instances");
+    static_assert(!LISTS || (SPLIT && MODE != MODE_TWO_LEVEL), "pixel lists: split items, one world-space tree");
     static_assert(!ROOMY || (LISTS && PIPELINED), "the six-workgroup build is for the pipelined form with lists");
     __shared__ __align__(16) uint32_t s_lists[LISTS ? (RENDER_BLOCK / WAVE) * (PIPELINED ? RRT_ITEM_RING : 1) * LIST_PIXELS * PIXEL_LIST_DWORDS : 1];
     // RENDER_STACK entries per lane of the traversal stack live in LDS, the rest in private memory (six workgroups per
     // CU, seven in the pipelined form, whose large scenes gain more from the extra wavefront than they lose to its
     // spills).  Instanced scenes add six floats per lane for the world-space ray of a lane that walks inside a mesh.
-    constexpr int K = INST ? RRT_INST_STACK : RENDER_STACK;
+    // (an unrolled scene's kernel with lists keeps RRT_UL_STACK_CUT entries fewer in LDS: its table of instance transforms
+    // and the lists would otherwise leave room for six workgroups per CU instead of seven)
+    constexpr int K = INST ? RRT_INST_STACK : (MODE == MODE_UNROLLED && LISTS ? RENDER_STACK - RRT_UL_STACK_CUT : RENDER_STACK);
     __shared__ int s_stack[K * RENDER_BLOCK];
     __shared__ float s_wray[INST ? 6 * RENDER_BLOCK : 1];
     __shared__ uint32_t s_items[(RENDER_BLOCK / WAVE) * 8 * RRT_ITEM_RING];  // per wavefront: the records of its work items in flight
     // Unrolled scenes: the instance transforms a triangle leaf needs (offset, sin, cos: the first 32 bytes of a record)
     // are copied to LDS once per workgroup when they fit, slot 0 = the identity record in front of the table.
-    __shared__ vec4f s_xf[MODE == MODE_UNROLLED ? 2 * XF_LDS_SLOTS : 1];
+    __shared__ vec4f s_xf[MODE == MODE_UNROLLED && !(LISTS && RRT_UL_XF == 0) ? 2 * XF_LDS_SLOTS : 1];
     const lds_float4* xf_lds = nullptr;
-    if (MODE == MODE_UNROLLED && S.inst_count + 1u <= (uint32_t)XF_LDS_SLOTS) {
+    if (MODE == MODE_UNROLLED && !(LISTS && RRT_UL_XF == 0) && S.inst_count + 1u <= (uint32_t)XF_LDS_SLOTS) {
         const vec4f* src = reinterpret_cast<const vec4f*>(S.insts - 1);  // four 16-byte quarters per 64-byte record
         for (uint32_t i = threadIdx.x; i < 2u * (S.inst_count + 1u); i += RENDER_BLOCK) s_xf[i] = src[(i >> 1) * 4u + (i & 1u)];
         __syncthreads();
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
         if (COUNT && first_active_lane()) cnt.wave_prims++;
         for (uint32_t i = 0; i < n_listed; ++i) {
             if (__uint_as_float(list[3u + 2u * i]) > T.best.t) break;
-            test_listed_leaf<COUNT>(S, list[2u + 2u * i], o, d, S.t_min, T.best, cnt);
+            test_listed_leaf<COUNT, MODE>(S, list[2u + 2u * i], o, d, S.t_min, T.best, cnt, xf_lds);
         }
     };
 
@@ -679,6 +690,9 @@ static hipError_t launch_render_variant(const SceneDev& S, const RenderGeom& G, 
 
 // The instantiations for unrolled scenes (rrt_kernels_unrolled.hip).
 hipError_t launch_render_unrolled(bool count_visits, bool pipelined, bool scaled, const SceneDev& S, const RenderGeom& G, float* out,
+                                  unsigned long long* d_counters, unsigned int* d_heads, int cu_count, uint32_t max_blocks_per_cu,
+                                  hipStream_t stream);
+hipError_t launch_render_unrolled_lists(bool count_visits, bool pipelined, bool scaled, const SceneDev& S, const RenderGeom& G, float* out,
                                   unsigned long long* d_counters, unsigned int* d_heads, int cu_count, uint32_t max_blocks_per_cu,
                                   hipStream_t stream);
 

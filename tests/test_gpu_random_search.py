@@ -34,10 +34,12 @@ def test_every_form_of_the_render_kernel_gives_the_same_image_on_random_scenes()
 
 def test_pixel_lists_give_the_same_image_on_random_scenes():
     """Primary rays resolved against per-pixel candidate lists (both forms of the kernel's loop over items, both
-    register budgets) against the walked frame: bit-identical on 300 random scenes and cameras."""
+    register budgets) against the walked frame: bit-identical on 300 random scenes and cameras without instances and
+    on 150 with instanced meshes (unrolled: the lists name primitives together with their instance)."""
     import stress_lists
 
     assert stress_lists.run(300, 7, verbose=False) == 0
+    assert stress_lists.run(150, 8, verbose=False, instanced=True) == 0
 
 
 def test_same_seed_frames_match_the_oracle_on_random_scenes():

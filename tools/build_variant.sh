@@ -15,6 +15,7 @@ else
     K1=csrc/rrt_kernels.o
 fi
 /opt/rocm/bin/hipcc $BASE "$@" -c csrc/rrt_kernels_unrolled.hip -o exp_libs/${NAME}_u.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o exp_libs/$NAME.so $K1 exp_libs/${NAME}_u.o csrc/lbvh_build.o csrc/rrt_api.o csrc/scene_build.o csrc/bvh_builder.o host/gltf_loader.o host/png_writer.o -lpthread -ldl
-rm -f exp_libs/$NAME.o exp_libs/${NAME}_u.o
+/opt/rocm/bin/hipcc $BASE -mllvm -amdgpu-sched-strategy=${UL_SCHED:-iterative-maxocc} "$@" -c csrc/rrt_kernels_unrolled_lists.hip -o exp_libs/${NAME}_ul.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o exp_libs/$NAME.so $K1 exp_libs/${NAME}_u.o exp_libs/${NAME}_ul.o csrc/lbvh_build.o csrc/rrt_api.o csrc/scene_build.o csrc/bvh_builder.o host/gltf_loader.o host/png_writer.o -lpthread -ldl
+rm -f exp_libs/$NAME.o exp_libs/${NAME}_u.o exp_libs/${NAME}_ul.o
 echo built exp_libs/$NAME.so

@@ -3,7 +3,9 @@
     python tools/stress_lists.py [--cases 300] [--seed 1]      (on the GPU box)
 Triangle soups of 20 .. 20000 triangles of very different sizes (needles, slivers, triangles larger than the scene),
 with spheres and rectangles thrown in, seen from outside, from inside and from touching distance, at fields of view
-from 0.5 to 175 degrees, on frames of 1 .. 90 pixels a side; both forms of the kernel's loop over items."""
+from 0.5 to 175 degrees, on frames of 1 .. 90 pixels a side; both forms of the kernel's loop over items.
+--instanced: the scenes of tools/stress_forms.py with meshes of triangles, spheres and cuboids under Translate(RotateY),
+unrolled into one tree (the lists then name a primitive together with its instance)."""
 import argparse
 import os
 import sys
@@ -11,6 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def random_flat_scene(rrt, np, g):
@@ -55,16 +58,21 @@ def random_flat_scene(rrt, np, g):
     return s, f"n {n} scale {scale:.3g} kind {kind} dist {dist:.3g} fov {fov} cam_len {cam_len:.3g}"
 
 
-def run(cases, seed, only=-1, verbose=True):
+def run(cases, seed, only=-1, verbose=True, instanced=False):
     import numpy as np
     import rrt_pkg
+    import stress_forms
 
     rrt = rrt_pkg.load()
     g = np.random.default_rng(seed)
     bad = 0
     listed_total = 0
     for case in range(cases):
-        s, what = random_flat_scene(rrt, np, g)
+        if instanced:
+            s, n_tris, scale = stress_forms.random_scene(rrt, np, g, True)
+            what = f"instanced n {n_tris} scale {scale:.3g}"
+        else:
+            s, what = random_flat_scene(rrt, np, g)
         w, h = int(g.integers(1, 91)), int(g.integers(1, 91))
         spp, chunks = (16, 8) if g.integers(0, 2) else (37, 16)
         case_seed = int(g.integers(1, 1 << 30))
@@ -99,8 +107,9 @@ def main():
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", type=int, default=-1, help="render this case only, and compare both renders with the oracle's")
+    ap.add_argument("--instanced", action="store_true", help="scenes with instanced meshes (unrolled)")
     args = ap.parse_args()
-    sys.exit(1 if run(args.cases, args.seed, args.only) else 0)
+    sys.exit(1 if run(args.cases, args.seed, args.only, instanced=args.instanced) else 0)
 
 
 if __name__ == "__main__":
