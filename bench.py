@@ -147,20 +147,28 @@ def cpu_baseline(scene, width, height, spp_full, seed, mode_name, budget_s=30.0)
             "samples_per_s": sw * sh * spp / dt, "rays": rays, "seconds": dt}
 
 
-def measured_pmc(config: int, width: int, height: int):
+def measured_pmc(config: int, width: int, height: int, spp: int):
     """Hardware-counter figures of k_render from the committed rocprofv3 PMC passes (profiles/pmc_per_launch.json, written
     by tools/pmc_to_json.py from tools/prof.sh output), or None when this scene and frame size have not been profiled.
-    The figures are per launch of the profiled sample count; the kernel's cost per ray does not depend on the sample
-    count, so they are used per ray."""
+    The figures are per launch of the profiled sample count and are used per ray: the record profiled at this launch's
+    sample count ("<config>@<spp>spp") if there is one; for the ten-million-triangle scenes, whose launches of 128
+    samples and more run another form of the kernel (primary rays from per-pixel lists), the record of such a launch;
+    else the configuration's default record."""
     path = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
     try:
         with open(path) as f:
-            row = json.load(f).get(str(config))
+            table = json.load(f)
     except (OSError, ValueError):
         return None
-    if not row or (row["width"], row["height"]) != (width, height) or not row.get("rays_per_launch"):
-        return None
-    return row
+    keys = [f"{config}@{spp}spp"]
+    if config in (5, 6) and spp >= 128:
+        keys.append(f"{config}@256spp")
+    keys.append(str(config))
+    for key in keys:
+        row = table.get(key)
+        if row and (row["width"], row["height"]) == (width, height) and row.get("rays_per_launch"):
+            return dict(row, key=key)
+    return None
 
 
 def main():
@@ -241,8 +249,8 @@ def main():
     # seven wavefronts per SIMD; rrt_tuning.list_waves): three launches until the choice stands, whatever --warmup says.
     for _ in range(max(0, 3 - args.warmup)):
         step(False)
-    # One more untimed step on rank 0: the frame as the timed steps render it (on scenes without instances: work items of
-    # a few pixels x many sample chunks) against the same sample slice rendered with whole 8x8 tiles as items.  Every
+    # One more untimed step on rank 0: the frame as the timed steps render it (where the library cuts it that way: work items of
+    # a few pixels x many sample chunks, primary rays from per-pixel lists) against the same sample slice rendered with whole 8x8 tiles as items.  Every
     # pixel's chunk sums are formed by one lane in sample order either way, so the two must agree in every bit and in
     # the number of rays; a difference ends the benchmark.
     frame_check = None
@@ -298,7 +306,7 @@ def main():
         algo_bytes = rays_per_step * bytes_per_ray + width * height * 12.0
         k_ms = float(np.mean(kernel_ms))
         k_s = k_ms * 1e-3
-        pmc = measured_pmc(args.config, width, height)
+        pmc = measured_pmc(args.config, width, height, spp)
         roof = {"kernel": "k_render", "kernel_ms": k_ms, "rays_per_launch": rays_per_step, "samples_per_launch": samples,
                 "nodes_per_ray": nodes_per_ray, "prims_per_ray": prims_per_ray, "bytes_per_ray": bytes_per_ray,
                 # what the rays read and write by the algorithm's own count, served mostly by L1 / L2 / Infinity Cache:
@@ -335,7 +343,7 @@ def main():
                 "l1_addr_floor_frac": pmc.get("sq_insts_vmem_rd", 0.0) * per_ray * rays_per_step * L1_CYCLES_PER_WAVE_LOAD / (CUS * k_s * GPU_GHZ * 1e9),
                 "l1_addr_busy_frac": pmc.get("ta_busy_frac"),
                 "waves_per_simd": pmc.get("waves_per_simd"),
-                "pmc_source": f"profiles/pmc_per_launch.json [{args.config}] ({pmc.get('source', 'rocprofv3 --pmc, tools/prof.sh')}), profiled at {pmc.get('spp_per_gpu')} spp, used per ray"})
+                "pmc_source": f"profiles/pmc_per_launch.json [{pmc['key']}] ({pmc.get('source', 'rocprofv3 --pmc, tools/prof.sh')}), profiled at {pmc.get('spp_per_gpu')} spp, used per ray"})
             # the unit the kernel fills most is the one that bounds it: the SIMDs' issue slots (vector instructions at two
             # cycles each), the address unit of the vector L1 (16 cycles per wavefront load instruction), or HBM
             l1_rate = pmc.get("sq_insts_vmem_rd", 0.0) * per_ray * rays_per_step / k_s / 1e9  # G wavefront loads/s

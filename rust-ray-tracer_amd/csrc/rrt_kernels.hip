@@ -495,7 +495,7 @@ hipError_t launch_render(const SceneDev& S, uint32_t width, uint32_t height, uin
             case 1u: e = launch_render_variant<MODE_FLAT, false, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
             default: e = launch_render_variant<MODE_FLAT, false, false, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
         }
-    } else if (pix_log2 != 6u) {  // (scenes without instances: the items are split)
+    } else if (pix_log2 != 6u) {  // (scenes without instances: the items are split, their primary rays walk)
         switch ((scaled ? 4u : 0u) | (count_visits ? 2u : 0u) | (pipelined ? 1u : 0u)) {
             case 7u: e = launch_render_variant<MODE_FLAT, true, true, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;
             case 6u: e = launch_render_variant<MODE_FLAT, true, false, true, true>(S, G, out, d_counters, d_heads, cu_count, tuning.blocks_per_cu, stream); break;

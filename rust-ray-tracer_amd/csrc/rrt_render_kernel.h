@@ -1,7 +1,7 @@
 // rrt_render_kernel.h -- the persistent path-tracing megakernel k_render and the launcher of one instantiation of it.
-// Included by the two translation units that instantiate it: rrt_kernels.hip (scenes without instances, two-level
-// walk) and rrt_kernels_unrolled.hip (unrolled instances), which are compiled with different scheduling strategies
-// (the Makefile says which and why).
+// Included by the three translation units that instantiate it: rrt_kernels.hip (scenes without instances, two-level
+// walk), rrt_kernels_unrolled.hip (unrolled instances) and rrt_kernels_unrolled_lists.hip (unrolled instances, primary
+// rays from per-pixel lists), which are compiled with different scheduling strategies (the Makefile says which and why).
 //
 // k_render is a persistent-wavefront kernel: the grid is sized to what the chip holds at once, and every
 // 64-lane wavefront pulls work items from eight queues (one per group of workgroups that share an XCD).
@@ -121,7 +121,7 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #endif
 // SCALED: the node steps use the scaled form of the slab arithmetic (rrt_device.h: trav_set_ray_scaled), which the host
 // selects when the scene is walked on one grid and its camera's ray directions are of ordinary magnitude.
-// SPLIT (scenes without instances): an item's 64 lanes are 2^G.pix_log2 pixels times several of their
+// SPLIT (scenes without instances; unrolled scenes together with LISTS): an item's 64 lanes are 2^G.pix_log2 pixels times several of their
 // sample chunks instead of 64 pixels times one (launch_render picks the split); a template parameter because the
 // general index arithmetic costs the other scenes 1-3 % when it is merely switched off at run time.
 // LISTS (split items of at most LIST_PIXELS pixels, scenes walked as one world-space tree): a kernel run before this one

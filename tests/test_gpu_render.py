@@ -713,3 +713,37 @@ def test_flattened_workload_takes_pixel_lists(rrt, oracle):
     close = np.isclose(accum, ref, rtol=1e-4, atol=1e-5).all(axis=-1)
     assert close.mean() >= 0.98 and rel_l1(accum, ref) <= 2e-3
     r.close()
+
+
+def test_pixel_lists_with_more_instances_than_the_lds_table_holds(rrt):
+    """An unrolled scene of 200 instances: the render kernel's LDS copy of the instance transforms holds 127, so the
+    listed primitives' transforms come from device memory.  Same rays and image as the walk, bit for bit, in both forms
+    of the loop over items."""
+    from rust_ray_tracer_amd import scenes
+
+    s = rrt.Scene()
+    grey = s.add_material(rrt.Lambertian(0.7, 0.7, 0.7))
+    metal = s.add_material(rrt.Metal((0.8, 0.8, 0.9), 0.1))
+    light = s.add_material(rrt.DiffuseLight(300.0, 300.0, 300.0))
+    m = s.new_mesh()
+    s.add_triangles(scenes.blob_mesh(6, 7, 0.45, 0.2, seed=9), grey, mesh=m)
+    s.add_sphere((0.0, 0.6, 0.0), 0.15, metal, mesh=m)
+    blob = s.finish_mesh(m)
+    for k in range(200):
+        s.add_instance(blob, angle_deg=17.0 * k, offset=((k % 20 - 9.5) * 1.1, 0.02 * (k % 7), (k // 20 - 4.5) * 1.1))
+    s.add_sphere((0.0, 8.0, 0.0), 0.5, light)
+    s.add_sphere_light((0.0, 8.0, 0.0), 0.5)
+    s.camera = rrt.Camera(16.0 / 9.0, 50.0, scenes.look_at_c2w((1.0, 9.0, 14.0), (0.0, 0.0, 0.0)))
+    s.background = (0.05, 0.06, 0.08)
+    r = rrt.Renderer(seed=5)
+    info = r.upload(s)
+    assert info.unrolled_instances == 200
+    w, h, spp = 160, 90, 32
+    r.set_tuning(overlap_items=1, split_items=1, chunks=8, pixel_lists=0)
+    plain, s0 = r.render(w, h, spp)
+    for overlap in (0, 1):
+        r.set_tuning(overlap_items=overlap, pixel_lists=1)
+        img, s1 = r.render(w, h, spp)
+        assert r.info().pixel_list_permille > 500
+        assert s0.rays == s1.rays and np.array_equal(plain, img), overlap
+    r.close()
