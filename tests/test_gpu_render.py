@@ -638,7 +638,8 @@ def test_instanced_workload_at_full_size(rrt, oracle):
     """Benchmark configuration 5 (a 100k-triangle mesh x 100 Translate(RotateY(..)) instances, reference
     src/geometry/transform.rs:22-31,99-130) through the instanced form of the render kernel at its full 7680x4320 frame
     and a few samples: bitwise reproducibility, sample slices that add up, ray bounds, two independent estimates that
-    agree -- and a crop-sized same-seed frame against the oracle."""
+    agree -- a crop-sized same-seed frame against the oracle -- and a 128-sample frame, which takes per-pixel candidate
+    lists, against the walked one."""
     from rust_ray_tracer_amd import scenes
 
     scene = scenes.synthetic_instanced(rrt, helpers.ASSETS)
@@ -668,6 +669,14 @@ def test_instanced_workload_at_full_size(rrt, oracle):
     assert abs(int(st.rays) - ref_rays) <= 2
     close = np.isclose(accum, ref, rtol=1e-4, atol=1e-5).all(axis=-1)
     assert close.mean() >= 0.99 and rel_l1(accum, ref) <= 2e-3
+    # from 128 samples on the library cuts the frame into items of 8 pixels x 8 chunks whose primary rays take per-pixel
+    # candidate lists (entries name a triangle together with its instance): against whole tiles that walk, bit for bit
+    w2, h2 = 1920, 1080
+    listed, sl = r.render(w2, h2, 128)
+    assert sl.chunks == 8 and r.info().pixel_list_permille > 300, (sl.chunks, r.info().pixel_list_permille)
+    r.set_tuning(split_items=0, pixel_lists=0, chunks=8)
+    walked, swk = r.render(w2, h2, 128)
+    assert swk.rays == sl.rays and np.array_equal(listed, walked)
     r.close()
 
 
