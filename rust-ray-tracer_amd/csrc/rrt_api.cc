@@ -696,6 +696,14 @@ static rrt_status render_impl(rrt_ctx* c, uint32_t width, uint32_t height, uint3
     // taken from the scene's last render whose statistics were read; until one was, every pixel is assumed to.
     tuning.pixel_lists = tn.pixel_lists != RRT_TUNE_AUTO ? tn.pixel_lists : (lists_possible && (float)spp * c->list_share >= 32.0f ? 1u : 0u);
     if (tn.pixel_list_len != RRT_TUNE_AUTO) tuning.pixel_list_len = tn.pixel_list_len;
+    if (big_scene && huge_scene && !noalloc && render_takes_pixel_lists(c->sdev, width, height, n_chunks, tuning)) {
+        // a multi-million-node scene whose primary rays take lists: the walks of a trip are then all bounce rays, and the
+        // straggler threshold of the other large scenes is the better one again, as are narrower bands (measured on
+        // MI355X, 256 spp at 8K: leave_walk 8 / 12 / 20 / 28 -> flat 2050 / 2019 / 2027 / 2091 ms, unrolled 2189 / 2166 /
+        // 2195 / 2288; bands of 32 / 64 / 128 tiles -> flat 2034 / 2035 / 2027, unrolled 2162 / 2169 / 2195)
+        if (tn.leave_walk == RRT_TUNE_AUTO) tuning.leave_walk = RenderTuning().leave_walk;
+        if (tn.band_tiles == RRT_TUNE_AUTO && width >= 7000u) tuning.band_tiles = 64u;
+    }
     int waves_slot = -1;
     if (tn.list_waves != RRT_TUNE_AUTO) {
         tuning.list_waves = tn.list_waves;
