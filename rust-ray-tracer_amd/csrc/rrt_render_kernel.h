@@ -107,6 +107,9 @@ __device__ __forceinline__ uint32_t queue_begin(uint32_t q, uint32_t n_work) {
 #ifndef RRT_ONE_LIST_ROUNDS
 #define RRT_ONE_LIST_ROUNDS 2  // one-item form with pixel lists: rounds of a shade phase (the new samples of all but the last take their lists)
 #endif
+#ifndef RRT_UL_STEPS
+#define RRT_UL_STEPS 5  // unrolled scenes with lists: node steps between two votes of the pipelined form (the walks are bounce rays only)
+#endif
 #ifndef RRT_UL_STACK_CUT
 #define RRT_UL_STACK_CUT 4  // unrolled scenes with lists: entries of the traversal stack moved from LDS to private memory
 #endif
@@ -511,7 +514,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         // idle lane slots of this node pass, by what the idle lanes are waiting for
                         // (the pass is as long as the lane that stayed in it longest)
                         const uint32_t nodes0 = cnt.nodes;
-                        trav_nodes<MODE, COUNT, K, (MODE == MODE_UNROLLED ? RRT_UNROLLED_STEPS : RRT_PIPE_STEPS), SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, (MODE == MODE_UNROLLED ? (LISTS ? RRT_UL_STEPS : RRT_UNROLLED_STEPS) : RRT_PIPE_STEPS), SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                         uint32_t steps = cnt.nodes - nodes0;
                         for (int off = 32; off > 0; off >>= 1) steps = max(steps, (uint32_t)__shfl_xor((int)steps, off, WAVE));
 #ifdef RRT_COUNT_NORAY  // experiment: the second idle counter counts the lanes that have no ray at all instead
@@ -531,7 +534,7 @@ __global__ __launch_bounds__(RENDER_BLOCK, MODE == MODE_TWO_LEVEL ? RRT_INST_WAV
                         }
 #endif
                     } else {
-                        trav_nodes<MODE, COUNT, K, (MODE == MODE_UNROLLED ? RRT_UNROLLED_STEPS : RRT_PIPE_STEPS), SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
+                        trav_nodes<MODE, COUNT, K, (MODE == MODE_UNROLLED ? (LISTS ? RRT_UL_STEPS : RRT_UNROLLED_STEPS) : RRT_PIPE_STEPS), SCALED>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, share, lim, deep, wray);
                     }
                 }
                 if (T.cur < 0 && T.cur != REF_DONE && !(INST && trav_due(T.cur))) trav_leaf<MODE, COUNT, K, true>(S, o, d, S.t_min, RENDER_BLOCK, T, cnt, lim, deep, wray, xf_lds);
