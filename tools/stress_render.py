@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def run(cases, seed, verbose=True, flat_only=False, only=-1):
+def run(cases, seed, verbose=True, flat_only=False, only=-1, lists=False):
     import numpy as np
     import rrt_pkg
     from oracle import oracle
@@ -39,14 +39,23 @@ def run(cases, seed, verbose=True, flat_only=False, only=-1):
             s, what = stress_lists.random_flat_scene(rrt, np, g)
         w, h = int(g.integers(4, 41)), int(g.integers(4, 41))
         spp = int(g.integers(1, 7))
+        if lists:
+            spp = 8  # one sample in each of the 8 chunks an item with lists needs
         case_seed = int(g.integers(1, 1 << 30))
         if s.triangle_count > 2000 or (only >= 0 and case != only):
             continue
         done += 1
         r = rrt.Renderer(seed=case_seed, unroll_instances=case % 2 == 0)
         r.upload(s)
+        if lists:  # primary rays from per-pixel candidate lists (scenes without instances and unrolled ones)
+            r.set_tuning(split_items=1, chunks=8, pixel_lists=1, overlap_items=case % 4 < 2)
         img, st = r.render(w, h, spp)
         rgb = r.tonemap(img, spp)
+        if lists and only >= 0:  # the same frame with primary rays that walk
+            listed_share = r.info().pixel_list_permille / 10.0
+            r.set_tuning(pixel_lists=0)
+            walked, sw = r.render(w, h, spp)
+            print(f"case {case}: {listed_share:.1f} % of the pixels listed; walked frame: rays {sw.rays} (with lists {st.rays}), {int((walked != img).any(axis=-1).sum())} pixels differ from the frame with lists")
         r.close()
         ref, ref_rays = oracle.OracleScene(s).render(w, h, spp, seed=case_seed)
         finite = np.isfinite(ref).all(axis=-1) & np.isfinite(img).all(axis=-1)
@@ -73,10 +82,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--lists", action="store_true", help="8 samples in 8 chunks, items of 8 pixels, primary rays from per-pixel candidate lists")
     ap.add_argument("--flat-only", action="store_true", help="no instanced scenes")
     ap.add_argument("--only", type=int, default=-1, help="render this case only and print its differing pixels")
     args = ap.parse_args()
-    sys.exit(1 if run(args.cases, args.seed, flat_only=args.flat_only, only=args.only) else 0)
+    sys.exit(1 if run(args.cases, args.seed, flat_only=args.flat_only, only=args.only, lists=args.lists) else 0)
 
 
 if __name__ == "__main__":
